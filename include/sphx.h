@@ -1,0 +1,214 @@
+/* sphx.h — C ABI of the MI355X-native DFSPH step loop (libsphx.so).
+ *
+ * This is the drop-in boundary behind yasph2d's `Solver` trait / particle-array surface.  Every entry point
+ * cites the reference interface (path:line relative to the yasph2d repository root) it replaces.  The Rust-side
+ * binding a maintainer would add (an `impl Solver for HipDfsphSolver` in src/sph/solver/) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `float* xy` arrays are interleaved {x,y} pairs, i.e. exactly the memory of a
+ *     `Vec<cgmath::Point2<f32>>` / `Vec<cgmath::Vector2<f32>>` (src/units.rs:2-4).
+ *   - every call returns an `int` status (SPHX_OK == 0).  Nothing aborts or throws across the boundary: the places
+ *     where the reference panics (dfsph.rs:223,378 `assert!(is_finite)`, neighborhood_search.rs:373 bounds panic,
+ *     Duration::from_secs_f32 on non-finite input) become error codes; sphx_last_error() gives the text.
+ *   - the caller owns every host pointer (borrowed for the duration of the call); the library owns all device memory.
+ *   - one context = one caller thread at a time (mirrors `&mut self` of Solver::simulation_step, solver/mod.rs:17).
+ *   - all device work runs on one HIP stream owned by the context; calls that return host data synchronise it.
+ */
+#ifndef SPHX_H
+#define SPHX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHX_ABI_VERSION 1
+
+/* ---- status codes ---- */
+enum {
+    SPHX_OK = 0,
+    SPHX_ERR_INVALID_ARGUMENT = 1,
+    SPHX_ERR_NO_DEVICE = 2,       /* no HIP device / HIP runtime error; the product has no CPU fallback */
+    SPHX_ERR_HIP = 3,
+    SPHX_ERR_NOT_READY = 4,       /* step called before upload / begin-finish out of order */
+    SPHX_ERR_NONFINITE = 5,       /* dfsph.rs:223,378 assert!(avg.is_finite()) */
+    SPHX_ERR_NEIGHBOR_PANIC = 6,  /* neighborhood_search.rs:373: 64 dynamic neighbours and a static hit (reference panics) */
+    SPHX_ERR_CAPACITY = 7,        /* internal table capacity exceeded (grid blocks / neighbour entries) */
+    SPHX_ERR_OUT_OF_DOMAIN = 8    /* a particle left the Morton domain the grid tables were sized for */
+};
+
+/* ---- stats.flags bits ---- */
+enum {
+    SPHX_FLAG_NEIGHBOR_CAP = 1u,            /* "particle has too many neighbors" (neighborhood_search.rs:361,376) */
+    SPHX_FLAG_DENSITY_ITER_CAP = 2u,        /* "Density error correction canceled" (dfsph.rs:236-245) */
+    SPHX_FLAG_DIVERGENCE_ITER_CAP = 4u,     /* "Divergence error correction canceled" (dfsph.rs:391-400) */
+    SPHX_FLAG_WARMUP = 8u                   /* this step ran the warm-up block (dfsph.rs:419-428) */
+};
+
+/* kernel kinds for sphx_update_densities (src/sph/smoothing_kernel/) */
+enum { SPHX_KERNEL_WENDLAND_C2 = 0, SPHX_KERNEL_POLY6 = 1, SPHX_KERNEL_SPIKY = 2 };
+
+typedef struct sphx_ctx sphx_ctx;
+
+/* Everything the reference hard-codes or derives from ConstantFluidProperties, as one POD.
+ * sphx_default_params() fills the values of the reference app (main.rs:85-89, dfsph.rs:49-55, xsph.rs:14,
+ * fluidparticleworld.rs:123, neighborhood_search.rs:478). */
+typedef struct sphx_params {
+    float smoothing_length;            /* h: DFSPHSolver::new(_, smoothing_length) dfsph.rs:43; also the search radius / cell size
+                                          (fluidparticleworld.rs:118, neighborhood_search.rs:466) */
+    float particle_mass;               /* ConstantFluidProperties::particle_mass() fluidparticleworld.rs:74-76 */
+    float fluid_density;               /* rho0, fluidparticleworld.rs:70-72 */
+    float particle_radius;             /* fluidparticleworld.rs:87-89 (CFL diameter = 2*radius, dfsph.rs:479) */
+    float gravity[2];                  /* FluidParticleWorld::gravity, fluidparticleworld.rs:98,123 */
+    float grid_min[2];                 /* GridProperties::grid_min, neighborhood_search.rs:478 */
+    float xsph_epsilon;                /* XSPHViscosityModel::epsilon, xsph.rs:8,14 */
+    float max_avg_density_error;       /* dfsph.rs:49 */
+    uint32_t max_density_iterations;   /* dfsph.rs:50 */
+    float max_divergence_error;        /* dfsph.rs:53 */
+    uint32_t max_divergence_iterations;/* dfsph.rs:54 */
+    uint32_t fixed_density_iterations; /* 0 = adaptive (reference behaviour); >0 = run exactly this many (parity/bench mode) */
+    uint32_t fixed_divergence_iterations;
+    int32_t device;                    /* HIP device ordinal */
+    uint32_t reserved[4];
+} sphx_params;
+
+/* Per-step report (the reference only println!s these; dfsph.rs:227-243,382-398). */
+typedef struct sphx_step_stats {
+    uint32_t density_iterations;       /* num_density_correction_iterations after the step (dfsph.rs:26) */
+    uint32_t divergence_iterations;    /* num_divergence_correction_iterations (dfsph.rs:33) */
+    uint32_t warmstart_density;        /* 1 if the kappa warm-start pass ran (dfsph.rs:199-205) */
+    uint32_t warmstart_divergence;     /* 1 if the stiffness warm-start pass ran (dfsph.rs:354-360) */
+    float avg_density_error;           /* last avg_density_error (dfsph.rs:221) */
+    float avg_divergence;              /* last avg_divergence (dfsph.rs:376) */
+    float dt_prev;                     /* dt the XSPH term used (dfsph.rs:433) */
+    float dt;                          /* dt of prediction/solve/advect (dfsph.rs:478-480) */
+    float vmax;                        /* sqrt(max |v + a*dt_prev|^2) handed to TimeManager (dfsph.rs:474-479) */
+    uint32_t flags;                    /* SPHX_FLAG_* */
+    uint32_t reserved;
+    uint64_t neighbor_entries;         /* sum of count_total over particles (length of the neighbour list buffer) */
+} sphx_step_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------------- */
+/* replaces DFSPHSolver::new (dfsph.rs:43-61) + the solver-owned part of FluidParticleWorld::new (fluidparticleworld.rs:104-127) */
+int sphx_default_params(float smoothing_factor, float particle_density, float fluid_density, sphx_params* out);
+int sphx_create(const sphx_params* params, sphx_ctx** out_ctx);
+void sphx_destroy(sphx_ctx* ctx);
+const char* sphx_last_error(const sphx_ctx* ctx); /* ctx may be NULL: returns the last creation error */
+uint32_t sphx_abi_version(void);
+
+/* ---- particle-array surface (fluidparticleworld.rs:11-23) ---------------------------------------------------- */
+/* Particles::boundary_particles + boundary_changed=true (fluidparticleworld.rs:181-195); rebuilt lazily like :247-252 */
+int sphx_set_boundary(sphx_ctx* ctx, const float* xy, uint32_t n);
+/* Particles::positions / velocities (vel_xy may be NULL = zero).  Drops nothing cached: like the reference, caches are
+ * rebuilt when the particle count differs from the cached arrays' length (dfsph.rs:419) or after sphx_clear_cached. */
+int sphx_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, uint32_t n);
+/* Any pointer may be NULL.  Arrays are in the library's current (cell-sorted) order — the reference also re-sorts in
+ * place every step (neighborhood_search.rs:121-140).  particle_id[i] = index the particle had in the last sphx_upload. */
+int sphx_download(sphx_ctx* ctx, float* pos_xy, float* vel_xy, float* density, uint32_t* particle_id);
+int sphx_download_boundary(sphx_ctx* ctx, float* xy, uint32_t* boundary_id);
+uint32_t sphx_num_particles(const sphx_ctx* ctx);  /* Particles::num_dynamic_particles  fluidparticleworld.rs:37 */
+uint32_t sphx_num_boundary(const sphx_ctx* ctx);   /* Particles::num_boundary_particles fluidparticleworld.rs:41 */
+
+/* ---- Solver trait (solver/mod.rs:12-18) ---------------------------------------------------------------------- */
+/* Solver::clear_cached_data (dfsph.rs:406-412) */
+int sphx_clear_cached(sphx_ctx* ctx);
+/* Solver::simulation_step is two-phase because the reference calls back into the caller-owned TimeManager mid-step:
+ *   phase A = dfsph.rs:419-477 (warm-up if needed, non-pressure accelerations + XSPH with dt_prev =
+ *             time_manager.simulation_step().as_secs_f32(), max |v + a*dt_prev|) -> *out_vmax = sqrt(max)
+ *   host    = dt = time_manager.update_simulation_step(2*radius, vmax).as_secs_f32()   (dfsph.rs:478-480)
+ *   phase B = dfsph.rs:484-524 (predict, constant-density loop, advect, re-grid, density+alpha, divergence loop, swap) */
+int sphx_step_begin(sphx_ctx* ctx, float dt_prev, float* out_vmax);
+int sphx_step_finish(sphx_ctx* ctx, float dt, sphx_step_stats* out_stats);
+
+/* ---- pieces of the path the reference exposes on FluidParticleWorld (driven by benches/) --------------------- */
+/* FluidParticleWorld::update_neighborhood_datastructure(vec![], vec![]) (fluidparticleworld.rs:235-261) */
+int sphx_update_neighborhood(sphx_ctx* ctx);
+/* FluidParticleWorld::update_densities(kernel) (fluidparticleworld.rs:197-231) */
+int sphx_update_densities(sphx_ctx* ctx, int kernel_kind);
+/* DFSPHSolver::compute_alpha_factors (dfsph.rs:68-97) on the current lists */
+int sphx_compute_alpha(sphx_ctx* ctx);
+
+/* ---- parity/inspection (not on the hot path) ------------------------------------------------------------------ */
+/* DFSPHSolver::{alpha_values, warmstart_kappa, warmstart_stiffness} (dfsph.rs:36-40); any pointer may be NULL */
+int sphx_download_solver_state(sphx_ctx* ctx, float* alpha, float* kappa, float* stiffness);
+/* NeighborLists (neighborhood_search.rs:262-300, 433-449) in canonical form: counts[2*i] = count_dynamic,
+ * counts[2*i+1] = count_total; lists = all particles' lists concatenated in particle order (the reference's
+ * start_index is thread-schedule dependent and is not part of the contract).  Either pointer may be NULL. */
+int sphx_download_neighbors(sphx_ctx* ctx, uint16_t* counts, uint32_t* lists, uint64_t* out_total_entries);
+/* CompactMortonCellGrid::cells (neighborhood_search.rs:34-37,142-165) incl. the sentinel; which: 0 dynamic, 1 static.
+ * Pass NULL arrays to query the count. */
+int sphx_download_cells(sphx_ctx* ctx, int which, uint32_t* first_particle, uint32_t* cidx, uint32_t* out_count);
+/* derived kernel constants: out[0..2] = Wendland {h_inv, normalizer, normalizer_grad} (wendland_quintic_c2.rs:24-30),
+ * out[3..5] = Poly6 {hsq, normalizer, normalizer_grad} (poly6.rs:16-23) */
+int sphx_get_constants(const sphx_ctx* ctx, float* out6);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+int sphx_synchronize(sphx_ctx* ctx);
+/* When enabled every kernel launch is bracketed by hipEvents on the context's stream; totals are kept per kernel name. */
+int sphx_profile_enable(sphx_ctx* ctx, int on);
+int sphx_profile_reset(sphx_ctx* ctx);
+/* Fills up to *inout_n records; names are NUL-terminated, <= 47 chars. */
+typedef struct sphx_kernel_time {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double algorithmic_bytes; /* sum over launches of the algorithmic byte count of DESIGN.md */
+} sphx_kernel_time;
+int sphx_profile_get(sphx_ctx* ctx, sphx_kernel_time* out, uint32_t* inout_n);
+
+/* ======================================================================================================================
+ * Host-side mirror of the reference's caller-side types (scene helpers, TimeManager, Solver object).  These exist so the
+ * C++ harness / Python drivers can play the role of the Rust application; a Rust host would keep using its own types.
+ * ====================================================================================================================== */
+typedef struct sphx_world sphx_world;   /* FluidParticleWorld (fluidparticleworld.rs:92-102) host arrays + properties */
+typedef struct sphx_timer sphx_timer;   /* TimeManager (timemanager.rs:72-92), simulation-step part only */
+typedef struct sphx_solver sphx_solver; /* Box<dyn Solver> (main.rs:50): HIP-backed DFSPHSolver */
+
+sphx_world* sphx_world_create(float smoothing_factor, float particle_density, float fluid_density); /* fluidparticleworld.rs:104 */
+void sphx_world_destroy(sphx_world* w);
+void sphx_world_properties(const sphx_world* w, float* out4); /* {smoothing_length, particle_mass, particle_radius, fluid_density} */
+void sphx_world_remove_all_fluid_particles(sphx_world* w);    /* fluidparticleworld.rs:129-132 */
+void sphx_world_remove_all_boundary_particles(sphx_world* w); /* fluidparticleworld.rs:134-137 */
+void sphx_world_add_fluid_rect(sphx_world* w, float x, float y, float width, float height, float jitter_amount); /* :140-166 */
+void sphx_world_add_boundary_thick_line(sphx_world* w, float sx, float sy, float ex, float ey, uint32_t thickness); /* :168-179 */
+void sphx_world_add_boundary_line(sphx_world* w, float sx, float sy, float ex, float ey); /* :181-195 */
+/* main.rs:177-196 `reset_fluid` with every coordinate multiplied by `scale` (scale 1 = the reference scene, ~4050 particles) */
+void sphx_world_reset_fluid(sphx_world* w, float scale);
+uint32_t sphx_world_num_dynamic_particles(const sphx_world* w);  /* fluidparticleworld.rs:37 */
+uint32_t sphx_world_num_boundary_particles(const sphx_world* w); /* fluidparticleworld.rs:41 */
+float* sphx_world_positions(sphx_world* w);   /* interleaved xy, length 2*num_dynamic */
+float* sphx_world_velocities(sphx_world* w);
+float* sphx_world_densities(sphx_world* w);
+float* sphx_world_boundary(sphx_world* w);
+uint32_t* sphx_world_particle_ids(sphx_world* w); /* valid after a solver step with sync enabled */
+void sphx_world_set_particles(sphx_world* w, const float* pos_xy, const float* vel_xy, uint32_t n);
+void sphx_world_set_boundary(sphx_world* w, const float* xy, uint32_t n);
+void sphx_world_set_gravity(sphx_world* w, float gx, float gy);
+
+uint64_t sphx_duration_from_secs_f32(float secs); /* std::time::Duration::from_secs_f32 -> nanoseconds (round-to-nearest-even) */
+float sphx_duration_as_secs_f32(uint64_t nanos);  /* Duration::as_secs_f32 */
+sphx_timer* sphx_timer_create_adaptive(uint64_t timestep_max_ns, uint64_t timestep_min_ns, float cfl_factor); /* timemanager.rs:44-58,105-129 */
+sphx_timer* sphx_timer_create_fixed(uint64_t timestep_ns);                                                     /* timemanager.rs:40 */
+void sphx_timer_destroy(sphx_timer* t);
+void sphx_timer_restart(sphx_timer* t);                                                     /* timemanager.rs:131-133 */
+uint64_t sphx_timer_simulation_step_ns(const sphx_timer* t);                                /* timemanager.rs:136-138 */
+uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float particle_diameter, float max_velocity); /* timemanager.rs:252-279 */
+uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t);
+uint32_t sphx_timer_num_steps(const sphx_timer* t);
+
+/* DFSPHSolver::new(XSPHViscosityModel::new(h), h) boxed as dyn Solver (main.rs:93-101).  `params` may be NULL (defaults from the world). */
+int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out);
+void sphx_solver_destroy(sphx_solver* s);
+void sphx_solver_clear_cached_data(sphx_solver* s); /* Solver::clear_cached_data */
+/* Solver::simulation_step(&mut world, &mut time_manager) (dfsph.rs:414).  sync_world != 0 copies positions/velocities/
+ * densities back into the host world before returning (what main.rs:242-258 draws from); 0 keeps them device-resident. */
+int sphx_solver_simulation_step(sphx_solver* s, sphx_world* w, sphx_timer* t, int sync_world, sphx_step_stats* out_stats);
+int sphx_solver_sync_world(sphx_solver* s, sphx_world* w); /* explicit download into the host world */
+sphx_ctx* sphx_solver_ctx(sphx_solver* s);
+const char* sphx_solver_last_error(const sphx_solver* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_H */

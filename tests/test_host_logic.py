@@ -1,0 +1,138 @@
+"""CPU tests of the host-side logic: Duration restatement, TimeManager dt law, scene helpers, and agreement between the
+product's host mirror (libsphx.so, no GPU needed for these entry points) and the oracle's independent restatement."""
+import itertools
+import struct
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import yasph2d_amd as y
+
+
+def exact_round_ns(f32):
+    """Duration::from_secs_f32 semantics (Rust >= 1.63): exact value * 1e9, round half to even."""
+    fr = Fraction(float(np.float32(f32))) * 10**9
+    q, r = divmod(fr.numerator, fr.denominator)
+    twice = 2 * r
+    if twice > fr.denominator or (twice == fr.denominator and q % 2 == 1):
+        q += 1
+    return q
+
+
+def test_duration_from_secs_f32_exact(oracle_lib, sphx_lib):
+    rng = np.random.default_rng(0)
+    vals = [0.0, 1.0 / 360.0, 1.0 / 24000.0, 1e-9, 0.5e-9, 1.5e-9, 2.5e-9, 0.006, 1.0, 3.75, 1e-12, 123.456]
+    vals += list(10.0 ** rng.uniform(-9, 1, 2000))
+    vals += [struct.unpack("f", struct.pack("I", int(b)))[0] for b in rng.integers(0x30000000, 0x42000000, 2000)]
+    for v in vals:
+        v = np.float32(v)
+        want = exact_round_ns(v)
+        assert oracle_lib.orc_duration_from_secs_f32(v) == want, v
+        assert sphx_lib.sphx_duration_from_secs_f32(v) == want, v
+
+
+def test_duration_as_secs_f32(oracle_lib, sphx_lib):
+    for ns in [0, 1, 41667, 2777778, 999999999, 1000000000, 1500000000, 123456789012]:
+        secs, nanos = divmod(ns, 10**9)
+        want = np.float32(secs) + np.float32(nanos) / np.float32(1e9)
+        assert np.float32(oracle_lib.orc_duration_as_secs_f32(ns)) == want
+        assert np.float32(sphx_lib.sphx_duration_as_secs_f32(ns)) == want
+
+
+def test_app_timer_constants():
+    # main.rs:123-124: 1/120/3 s and 1/60/400 s through from_secs_f32
+    t = y.TimeManager()
+    assert t.timestep_max_ns == exact_round_ns(np.float32(1.0) / np.float32(120.0) / np.float32(3.0)) == 2777778
+    assert t.timestep_min_ns == exact_round_ns(np.float32(1.0) / np.float32(60.0) / np.float32(400.0)) == 41667
+    assert t.simulation_step_ns() == t.timestep_min_ns  # timemanager.rs:106-109
+
+
+def test_update_simulation_step_law_matches_oracle(oracle_lib):
+    """timemanager.rs:252-279: clamp(cfl*0.4*d/(vmax+1e-5)) to [min, min(max, 2*prev)] — mirror vs oracle vs formula."""
+    from oracle.oracle import Oracle
+
+    o = Oracle()
+    t = y.TimeManager()
+    rng = np.random.default_rng(4)
+    prev = t.simulation_step_ns()
+    for vmax in list(rng.uniform(0, 20, 300)) + [0.0, 1e-6, 1000.0]:
+        vmax = np.float32(vmax)
+        d = np.float32(0.01)
+        cfl = exact_round_ns(np.float32(1.5) * np.float32(0.4) * d / (vmax + np.float32(0.00001)))
+        want = max(t.timestep_min_ns, min(min(t.timestep_max_ns, 2 * prev), cfl))
+        got = t.update_simulation_step(d, vmax)
+        assert got == want
+        assert oracle_lib.orc_timer_update(o.h, d, vmax) == want
+        prev = got
+
+
+def test_fixed_timer():
+    t = y.TimeManager(fixed_ns=1000000)
+    assert t.update_simulation_step(np.float32(0.01), np.float32(5.0)) == 1000000
+
+
+def test_scene_counts_and_properties():
+    w = y.FluidParticleWorld()
+    pr = w.properties()
+    # world(2.0, 10000, 100): h = 0.02, m = 0.01, radius = 0.005
+    assert pr["smoothing_length"] == np.float32(0.02) and pr["particle_mass"] == np.float32(0.01)
+    assert pr["particle_radius"] == np.float32(0.005)
+    w.reset_fluid(1.0)
+    assert w.num_dynamic_particles == 45 * 90 == 4050  # main.rs:181 -> fluidparticleworld.rs:143-146
+    assert w.num_boundary_particles == 6840
+    p = w.positions
+    step = np.float32(0.5) / np.float32(45)
+    # jitter in [0.5, 1.0) * step * 0.05 on top of the lattice (fluidparticleworld.rs:156-164)
+    lattice = np.stack(np.meshgrid(np.arange(45, dtype=np.float32), np.arange(90, dtype=np.float32)), -1).reshape(-1, 2) * step
+    off = p - (np.array([0.1, 0.7], np.float32) + lattice)
+    assert (off >= 0.5 * step * 0.05 * 0.999).all() and (off <= step * 0.05 * 1.001).all()
+    assert (w.velocities == 0).all()
+    w2 = y.FluidParticleWorld()
+    w2.reset_fluid(1.0)
+    np.testing.assert_array_equal(w2.positions, p)  # deterministic generator
+
+
+def test_scene_scaling():
+    w = y.FluidParticleWorld()
+    s = float(np.sqrt(40000 / 4050))
+    w.reset_fluid(s)
+    n = w.num_dynamic_particles
+    assert abs(n - 40000) / 40000 < 0.02
+    b = w.boundary_particles
+    assert b[:, 0].min() < -1.9 * s and b[:, 0].max() > 3.9 * s  # floor line from -2s to 4s (main.rs:192)
+
+
+def test_bench_world_counts():
+    from util import bench_world
+
+    pos, boundary = bench_world()
+    assert len(pos) == 8100  # update_densities.rs:78
+    assert 4300 <= len(boundary) <= 4500  # "~4420", SURVEY §3.5
+
+
+def test_properties_match_oracle():
+    from oracle.oracle import Oracle
+
+    o = Oracle().properties()
+    w = y.FluidParticleWorld().properties()
+    for k in o:
+        assert o[k] == w[k], k
+
+
+def test_sort9_network_is_a_sorting_network():
+    """The 25-comparator network hard-coded in csrc/sphx_kernels.hip (sort9), checked with the 0-1 principle."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(y.__file__), "csrc", "sphx_kernels.hip")).read()
+    body = src[src.index("void sort9("):]
+    body = body[:body.index("}\n")]
+    net = [(int(a), int(b)) for a, b in re.findall(r"SPHX_CE\(c(\d), c(\d)\)", body)]
+    assert len(net) == 25
+    for bits in itertools.product([0, 1], repeat=9):
+        a = list(bits)
+        for i, j in net:
+            if a[i] > a[j]:
+                a[i], a[j] = a[j], a[i]
+        assert a == sorted(a)

@@ -1,0 +1,159 @@
+"""ctypes binding of libsphx.so (include/sphx.h).  Fails loudly if the library is missing: there is no fallback."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsphx.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# status codes (sphx.h)
+OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY, ERR_NONFINITE, ERR_NEIGHBOR_PANIC, ERR_CAPACITY, ERR_OUT_OF_DOMAIN = range(9)
+FLAG_NEIGHBOR_CAP, FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_WARMUP = 1, 2, 4, 8
+KERNEL_WENDLAND_C2, KERNEL_POLY6, KERNEL_SPIKY = 0, 1, 2
+
+
+class SphxParams(C.Structure):
+    _fields_ = [
+        ("smoothing_length", C.c_float),
+        ("particle_mass", C.c_float),
+        ("fluid_density", C.c_float),
+        ("particle_radius", C.c_float),
+        ("gravity", C.c_float * 2),
+        ("grid_min", C.c_float * 2),
+        ("xsph_epsilon", C.c_float),
+        ("max_avg_density_error", C.c_float),
+        ("max_density_iterations", C.c_uint32),
+        ("max_divergence_error", C.c_float),
+        ("max_divergence_iterations", C.c_uint32),
+        ("fixed_density_iterations", C.c_uint32),
+        ("fixed_divergence_iterations", C.c_uint32),
+        ("device", C.c_int32),
+        ("reserved", C.c_uint32 * 4),
+    ]
+
+
+class SphxStepStats(C.Structure):
+    _fields_ = [
+        ("density_iterations", C.c_uint32),
+        ("divergence_iterations", C.c_uint32),
+        ("warmstart_density", C.c_uint32),
+        ("warmstart_divergence", C.c_uint32),
+        ("avg_density_error", C.c_float),
+        ("avg_divergence", C.c_float),
+        ("dt_prev", C.c_float),
+        ("dt", C.c_float),
+        ("vmax", C.c_float),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("neighbor_entries", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class SphxKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of libsphx.so via csrc/Makefile (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+
+
+# every symbol include/sphx.h declares: (restype, argtypes)
+_vp, _u16p = C.c_void_p, C.c_void_p
+_f, _u32, _u64, _i = C.c_float, C.c_uint32, C.c_uint64, C.c_int
+SIGNATURES = {
+    "sphx_abi_version": (_u32, []),
+    "sphx_default_params": (_i, [_f, _f, _f, C.POINTER(SphxParams)]),
+    "sphx_create": (_i, [C.POINTER(SphxParams), C.POINTER(_vp)]),
+    "sphx_destroy": (None, [_vp]),
+    "sphx_last_error": (C.c_char_p, [_vp]),
+    "sphx_set_boundary": (_i, [_vp, _vp, _u32]),
+    "sphx_upload": (_i, [_vp, _vp, _vp, _u32]),
+    "sphx_download": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "sphx_download_boundary": (_i, [_vp, _vp, _vp]),
+    "sphx_num_particles": (_u32, [_vp]),
+    "sphx_num_boundary": (_u32, [_vp]),
+    "sphx_clear_cached": (_i, [_vp]),
+    "sphx_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
+    "sphx_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
+    "sphx_update_neighborhood": (_i, [_vp]),
+    "sphx_update_densities": (_i, [_vp, _i]),
+    "sphx_compute_alpha": (_i, [_vp]),
+    "sphx_download_solver_state": (_i, [_vp, _vp, _vp, _vp]),
+    "sphx_download_neighbors": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
+    "sphx_download_cells": (_i, [_vp, _i, _vp, _vp, C.POINTER(_u32)]),
+    "sphx_get_constants": (_i, [_vp, _vp]),
+    "sphx_synchronize": (_i, [_vp]),
+    "sphx_profile_enable": (_i, [_vp, _i]),
+    "sphx_profile_reset": (_i, [_vp]),
+    "sphx_profile_get": (_i, [_vp, _vp, C.POINTER(_u32)]),
+    # host mirror
+    "sphx_world_create": (_vp, [_f, _f, _f]),
+    "sphx_world_destroy": (None, [_vp]),
+    "sphx_world_properties": (None, [_vp, _vp]),
+    "sphx_world_remove_all_fluid_particles": (None, [_vp]),
+    "sphx_world_remove_all_boundary_particles": (None, [_vp]),
+    "sphx_world_add_fluid_rect": (None, [_vp, _f, _f, _f, _f, _f]),
+    "sphx_world_add_boundary_thick_line": (None, [_vp, _f, _f, _f, _f, _u32]),
+    "sphx_world_add_boundary_line": (None, [_vp, _f, _f, _f, _f]),
+    "sphx_world_reset_fluid": (None, [_vp, _f]),
+    "sphx_world_num_dynamic_particles": (_u32, [_vp]),
+    "sphx_world_num_boundary_particles": (_u32, [_vp]),
+    "sphx_world_positions": (_vp, [_vp]),
+    "sphx_world_velocities": (_vp, [_vp]),
+    "sphx_world_densities": (_vp, [_vp]),
+    "sphx_world_boundary": (_vp, [_vp]),
+    "sphx_world_particle_ids": (_vp, [_vp]),
+    "sphx_world_set_particles": (None, [_vp, _vp, _vp, _u32]),
+    "sphx_world_set_boundary": (None, [_vp, _vp, _u32]),
+    "sphx_world_set_gravity": (None, [_vp, _f, _f]),
+    "sphx_duration_from_secs_f32": (_u64, [_f]),
+    "sphx_duration_as_secs_f32": (_f, [_u64]),
+    "sphx_timer_create_adaptive": (_vp, [_u64, _u64, _f]),
+    "sphx_timer_create_fixed": (_vp, [_u64]),
+    "sphx_timer_destroy": (None, [_vp]),
+    "sphx_timer_restart": (None, [_vp]),
+    "sphx_timer_simulation_step_ns": (_u64, [_vp]),
+    "sphx_timer_update_simulation_step": (_u64, [_vp, _f, _f]),
+    "sphx_timer_total_simulated_ns": (_u64, [_vp]),
+    "sphx_timer_num_steps": (_u32, [_vp]),
+    "sphx_solver_create_dfsph": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(_vp)]),
+    "sphx_solver_destroy": (None, [_vp]),
+    "sphx_solver_clear_cached_data": (None, [_vp]),
+    "sphx_solver_simulation_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(SphxStepStats)]),
+    "sphx_solver_sync_world": (_i, [_vp, _vp]),
+    "sphx_solver_ctx": (_vp, [_vp]),
+    "sphx_solver_last_error": (C.c_char_p, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsphx.so.  Raises if it has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950).  yasph2d_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class SphxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sphx error {code}: {msg}")
+        self.code = code

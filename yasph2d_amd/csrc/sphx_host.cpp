@@ -1,0 +1,389 @@
+// sphx_host.cpp — implementation of the host-side mirror (sphx_host.hpp) and its C exports (include/sphx.h, bottom half).
+#include "sphx_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace sph {
+
+static inline Vector operator-(Point a, Point b) { return Vector{a.x - b.x, a.y - b.y}; }
+static inline Point operator+(Point a, Vector b) { return Point{a.x + b.x, a.y + b.y}; }
+static inline Vector operator+(Vector a, Vector b) { return Vector{a.x + b.x, a.y + b.y}; }
+static inline Vector operator*(Vector a, Real s) { return Vector{a.x * s, a.y * s}; }
+static inline Vector operator/(Vector a, Real s) { return Vector{a.x / s, a.y / s}; }
+static inline Vector operator-(Vector a) { return Vector{-a.x, -a.y}; }
+
+// ---- Duration ---------------------------------------------------------------------------------------------------
+Duration Duration::from_secs_f32(Real secs) {
+    Duration d;
+    if (!(secs >= 0.0f) || std::isinf(secs)) return d;  // the reference panics; callers check finiteness first
+    uint32_t bits;
+    std::memcpy(&bits, &secs, 4);
+    const uint32_t bexp = (bits >> 23) & 0xFF;
+    uint64_t mant = bits & 0x7FFFFFu;
+    int exp2;  // secs == mant * 2^exp2 exactly
+    if (bexp == 0) {
+        exp2 = -149;
+    } else {
+        mant |= 0x800000u;
+        exp2 = (int)bexp - 150;
+    }
+    const unsigned __int128 num = (unsigned __int128)mant * 1000000000ull;
+    if (exp2 >= 0) {
+        d.ns = (uint64_t)(num << exp2);
+        return d;
+    }
+    const int sh = -exp2;
+    if (sh >= 100) return d;
+    const unsigned __int128 q = num >> sh;
+    const unsigned __int128 rem = num - (q << sh);
+    const unsigned __int128 half = (unsigned __int128)1 << (sh - 1);
+    uint64_t ns = (uint64_t)q;
+    if (rem > half || (rem == half && (ns & 1))) ns += 1;
+    d.ns = ns;
+    return d;
+}
+Real Duration::as_secs_f32() const {
+    const uint64_t secs = ns / 1000000000ull;
+    const uint32_t nanos = (uint32_t)(ns % 1000000000ull);
+    return (Real)secs + (Real)nanos / 1000000000.0f;
+}
+
+// ---- ConstantFluidProperties (fluidparticleworld.rs:52-90) ---------------------------------------------------------
+ConstantFluidProperties::ConstantFluidProperties(Real smoothing_factor, Real particle_density, Real fluid_density) {
+    smoothing_length_ = 2.0f * particle_radius_from_particle_density(particle_density) * smoothing_factor;
+    particle_density_ = particle_density;
+    fluid_density_ = fluid_density;
+}
+Real ConstantFluidProperties::num_particles_per_meter() const { return std::sqrt(particle_density_); }
+Real ConstantFluidProperties::particle_radius_from_particle_density(Real particle_density) { return 0.5f / std::sqrt(particle_density); }
+
+// ---- jitter generator ---------------------------------------------------------------------------------------------
+// The reference seeds rand 0.8 SmallRng with the particle count before the add (fluidparticleworld.rs:153) and draws a
+// cgmath Vector2 of two Standard f32 in [0,1).  SmallRng's stream is not reproducible without the crate (not vendored,
+// no lockfile), so the mirror defines its own generator: SplitMix64 seeded the same way, f32 = (top 24 bits) * 2^-24
+// (the bit recipe rand's Standard uses for f32).  Initial positions are INPUTS to the path, not part of its parity.
+struct SmallRngStandIn {
+    uint64_t state;
+    explicit SmallRngStandIn(uint64_t seed) : state(seed) {}
+    uint64_t next_u64() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    Real gen_f32() { return (Real)(uint32_t)(next_u64() >> 40) * (1.0f / 16777216.0f); }
+    Vector gen_vector() {
+        const Real x = gen_f32();
+        const Real y = gen_f32();
+        return Vector{x, y};
+    }
+};
+
+// ---- FluidParticleWorld ---------------------------------------------------------------------------------------------
+FluidParticleWorld::FluidParticleWorld(Real smoothing_factor, Real particle_density, Real fluid_density)
+    : properties(smoothing_factor, particle_density, fluid_density), gravity{0.0f, -9.81f}, boundary_changed(true) {}
+
+void FluidParticleWorld::remove_all_fluid_particles() {  // :129-132
+    particles.positions.clear();
+    particles.velocities.clear();
+    fluid_generation++;
+}
+void FluidParticleWorld::remove_all_boundary_particles() {  // :134-137 (the reference also clears velocities here)
+    particles.boundary_particles.clear();
+    particles.velocities.clear();
+    boundary_changed = true;
+    fluid_generation++;
+}
+
+void FluidParticleWorld::add_fluid_rect(Real rx, Real ry, Real rw, Real rh, Real jitter_amount) {  // :140-166
+    const Real num_particles_per_meter = properties.num_particles_per_meter() * 0.9f;
+    const size_t num_particles_x = std::max<size_t>(1, (size_t)(rw * num_particles_per_meter));
+    const size_t num_particles_y = std::max<size_t>(1, (size_t)(rh * num_particles_per_meter));
+    const size_t num_particles = num_particles_x * num_particles_y;
+    const size_t new_total = particles.positions.size() + num_particles;
+    particles.positions.reserve(new_total);
+    particles.velocities.resize(new_total, Vector{0, 0});
+    particles.densities.resize(new_total, 0.0f);
+
+    SmallRngStandIn rng((uint64_t)particles.positions.size());
+    const Point bottom_left{rx, ry};
+    const Real step = std::min(rw / (Real)num_particles_x, rh / (Real)num_particles_y);
+    const Real jitter_factor = step * jitter_amount;
+    for (size_t y = 0; y < num_particles_y; ++y) {
+        for (size_t x = 0; x < num_particles_x; ++x) {
+            const Vector jitter = (rng.gen_vector() * 0.5f + Vector{0.5f, 0.5f}) * jitter_factor;
+            particles.positions.push_back(bottom_left + jitter + Vector{step * (Real)x, step * (Real)y});
+        }
+    }
+    fluid_generation++;
+}
+
+void FluidParticleWorld::add_boundary_thick_line(Point start, Point end, uint32_t thickness_in_particles) {  // :168-179
+    const Vector d = end - start;
+    const Real mag = std::sqrt(d.x * d.x + d.y * d.y);
+    const Vector dir = d * (1.0f / mag);  // cgmath normalize() = self * (1 / magnitude)
+    const Vector dir_perpendicular{-dir.y, dir.x};
+    const Real thickness_world = (Real)thickness_in_particles / properties.num_particles_per_meter();
+    const Vector elongation = dir * thickness_world;
+    Vector offset = (-dir_perpendicular) * thickness_world;
+    const Vector step = dir_perpendicular * thickness_world / (Real)thickness_in_particles;
+    for (uint32_t k = 0; k < thickness_in_particles; ++k) {
+        add_boundary_line(start + offset, end + offset + elongation);
+        offset = offset + step;
+    }
+}
+
+void FluidParticleWorld::add_boundary_line(Point start, Point end) {  // :181-195
+    const Vector d = end - start;
+    const Real distance = std::sqrt(d.x * d.x + d.y * d.y);
+    const Real num_particles_per_meter = properties.num_particles_per_meter();
+    const size_t num_shadow_particles = std::max<size_t>(1, (size_t)std::ceil(distance * num_particles_per_meter));
+    particles.boundary_particles.reserve(particles.boundary_particles.size() + num_shadow_particles);
+    const Vector step = d / distance / num_particles_per_meter;
+    Point pos = start;
+    for (size_t k = 0; k < num_shadow_particles; ++k) {
+        particles.boundary_particles.push_back(pos);
+        pos = pos + step;
+    }
+    boundary_changed = true;
+}
+
+void reset_fluid(FluidParticleWorld& w, Real s) {  // main.rs:177-196
+    w.remove_all_fluid_particles();
+    w.remove_all_boundary_particles();
+    w.add_fluid_rect(0.1f * s, 0.7f * s, 0.5f * s, 1.0f * s, 0.05f);
+    w.add_boundary_thick_line(Point{0.0f * s, 2.5f * s}, Point{2.0f * s, 2.5f * s}, 4);
+    w.add_boundary_thick_line(Point{0.0f * s, 0.0f * s}, Point{2.0f * s, 0.0f * s}, 4);
+    w.add_boundary_thick_line(Point{0.0f * s, 0.0f * s}, Point{0.0f * s, 2.5f * s}, 4);
+    w.add_boundary_thick_line(Point{2.0f * s, 0.0f * s}, Point{2.0f * s, 2.5f * s}, 4);
+    w.add_boundary_thick_line(Point{0.0f * s, 0.6f * s}, Point{1.75f * s, 0.5f * s}, 2);
+    w.add_boundary_thick_line(Point{0.0f * s, 2.5f * s}, Point{2.0f * s, 2.5f * s}, 2);
+    w.add_boundary_thick_line(Point{-2.0f * s, -0.5f * s}, Point{4.0f * s, -0.5f * s}, 4);
+}
+
+// ---- TimeManager ------------------------------------------------------------------------------------------------------
+TimeManager TimeManager::adaptive(Duration tmax, Duration tmin, Real cfl) {
+    TimeManager t;
+    t.fixed = false;
+    t.timestep_max = tmax;
+    t.timestep_min = tmin;
+    t.cfl_factor = cfl;
+    t.simulation_step_ = tmin;  // timemanager.rs:106-109
+    return t;
+}
+TimeManager TimeManager::fixed_step(Duration step) {
+    TimeManager t;
+    t.fixed = true;
+    t.timestep_max = t.timestep_min = t.simulation_step_ = step;
+    return t;
+}
+void TimeManager::restart() {
+    simulation_step_ = fixed ? timestep_max : timestep_min;
+    num_simulation_steps = 0;
+    total_simulated_time = Duration{};
+}
+Duration TimeManager::update_simulation_step(Real particle_diameter, Real max_velocity) {  // timemanager.rs:252-279
+    if (!fixed) {
+        const Real VELOCITY_EPSILON = 0.00001f;
+        const Duration time_cfl = Duration::from_secs_f32(cfl_factor * 0.4f * particle_diameter / (max_velocity + VELOCITY_EPSILON));
+        const uint64_t upper_bound = std::min(timestep_max.ns, simulation_step_.mul(2).ns);
+        const uint64_t lower_bound = timestep_min.ns;  // AdaptiveTimeStepTarget::None (main.rs:125)
+        simulation_step_.ns = std::max(lower_bound, std::min(upper_bound, time_cfl.ns));
+    }
+    return simulation_step_;
+}
+void TimeManager::on_step_started() {
+    num_simulation_steps += 1;
+    total_simulated_time.ns += simulation_step_.ns;
+}
+
+// ---- HipDfsphSolver -----------------------------------------------------------------------------------------------------
+HipDfsphSolver::HipDfsphSolver(const FluidParticleWorld& world, const sphx_params* params) {
+    sphx_params p;
+    if (params) {
+        p = *params;
+    } else {
+        sphx_default_params(1.0f, 1.0f, 1.0f, &p);
+        p.smoothing_length = world.properties.smoothing_length();  // DFSPHSolver::new(xsph, smoothing_length) main.rs:100
+        p.particle_mass = world.properties.particle_mass();
+        p.fluid_density = world.properties.fluid_density();
+        p.particle_radius = world.properties.particle_radius();
+        p.gravity[0] = world.gravity.x;
+        p.gravity[1] = world.gravity.y;
+    }
+    last_status = sphx_create(&p, &ctx_);
+    if (last_status != SPHX_OK) {
+        last_error = sphx_last_error(nullptr);
+        ctx_ = nullptr;
+    }
+}
+HipDfsphSolver::~HipDfsphSolver() { sphx_destroy(ctx_); }
+
+void HipDfsphSolver::clear_cached_data() {  // dfsph.rs:406-412
+    if (!ctx_) return;
+    last_status = sphx_clear_cached(ctx_);
+    uploaded_n_ = (size_t)-1;  // next step re-reads the host world, like the reference which always reads it
+}
+
+void HipDfsphSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {  // dfsph.rs:414-525
+    if (!ctx_) {
+        last_status = SPHX_ERR_NO_DEVICE;
+        return;
+    }
+    auto fail = [&](int rc) {
+        last_status = rc;
+        last_error = sphx_last_error(ctx_);
+    };
+    int rc;
+    if (w.boundary_changed) {  // fluidparticleworld.rs:247-252
+        const auto& b = w.particles.boundary_particles;
+        if ((rc = sphx_set_boundary(ctx_, b.empty() ? nullptr : &b[0].x, (uint32_t)b.size()))) return fail(rc);
+        w.boundary_changed = false;
+    }
+    const size_t n = w.particles.positions.size();
+    if (n != uploaded_n_ || w.fluid_generation != uploaded_generation_) {
+        // The reference reads the world's Vecs directly; here they are (re)uploaded when the caller edited them.
+        if (w.particles.velocities.size() != n) w.particles.velocities.resize(n, Vector{0, 0});
+        if ((rc = sphx_upload(ctx_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr, (uint32_t)n)))
+            return fail(rc);
+        uploaded_n_ = n;
+        uploaded_generation_ = w.fluid_generation;
+    }
+    const Real dt_prev = tm.simulation_step().as_secs_f32();  // dfsph.rs:433
+    Real vmax = 0;
+    if ((rc = sphx_step_begin(ctx_, dt_prev, &vmax))) return fail(rc);
+    const Real dt = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // dfsph.rs:478-480
+    if ((rc = sphx_step_finish(ctx_, dt, &last_stats))) return fail(rc);
+    last_status = SPHX_OK;
+    if (sync_every_step) {
+        if ((rc = sync_world(w))) return fail(rc);
+    }
+}
+
+int HipDfsphSolver::sync_world(FluidParticleWorld& w) {
+    if (!ctx_) return SPHX_ERR_NO_DEVICE;
+    const size_t n = sphx_num_particles(ctx_);
+    w.particles.positions.resize(n);
+    w.particles.velocities.resize(n);
+    w.particles.densities.resize(n);
+    w.particles.particle_ids.resize(n);
+    int rc = sphx_download(ctx_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr,
+                           n ? w.particles.densities.data() : nullptr, n ? w.particles.particle_ids.data() : nullptr);
+    // host arrays now equal the device state: no re-upload needed
+    uploaded_generation_ = w.fluid_generation;
+    uploaded_n_ = n;
+    return rc;
+}
+
+}  // namespace sph
+
+// =====================================================================================================================
+// C exports (include/sphx.h, host-side mirror section)
+// =====================================================================================================================
+struct sphx_world {
+    sph::FluidParticleWorld w;
+    sphx_world(float a, float b, float c) : w(a, b, c) {}
+};
+struct sphx_timer {
+    sph::TimeManager t;
+};
+struct sphx_solver {
+    sph::HipDfsphSolver s;
+    sphx_solver(const sph::FluidParticleWorld& w, const sphx_params* p) : s(w, p) {}
+};
+
+extern "C" {
+
+sphx_world* sphx_world_create(float smoothing_factor, float particle_density, float fluid_density) {
+    if (!(particle_density > 0)) return nullptr;
+    return new sphx_world(smoothing_factor, particle_density, fluid_density);
+}
+void sphx_world_destroy(sphx_world* w) { delete w; }
+void sphx_world_properties(const sphx_world* w, float* out4) {
+    out4[0] = w->w.properties.smoothing_length();
+    out4[1] = w->w.properties.particle_mass();
+    out4[2] = w->w.properties.particle_radius();
+    out4[3] = w->w.properties.fluid_density();
+}
+void sphx_world_remove_all_fluid_particles(sphx_world* w) { w->w.remove_all_fluid_particles(); }
+void sphx_world_remove_all_boundary_particles(sphx_world* w) { w->w.remove_all_boundary_particles(); }
+void sphx_world_add_fluid_rect(sphx_world* w, float x, float y, float width, float height, float jitter) {
+    w->w.add_fluid_rect(x, y, width, height, jitter);
+}
+void sphx_world_add_boundary_thick_line(sphx_world* w, float sx, float sy, float ex, float ey, uint32_t thickness) {
+    w->w.add_boundary_thick_line(sph::Point{sx, sy}, sph::Point{ex, ey}, thickness);
+}
+void sphx_world_add_boundary_line(sphx_world* w, float sx, float sy, float ex, float ey) {
+    w->w.add_boundary_line(sph::Point{sx, sy}, sph::Point{ex, ey});
+}
+void sphx_world_reset_fluid(sphx_world* w, float scale) { sph::reset_fluid(w->w, scale); }
+uint32_t sphx_world_num_dynamic_particles(const sphx_world* w) { return (uint32_t)w->w.particles.num_dynamic_particles(); }
+uint32_t sphx_world_num_boundary_particles(const sphx_world* w) { return (uint32_t)w->w.particles.num_boundary_particles(); }
+float* sphx_world_positions(sphx_world* w) { return w->w.particles.positions.empty() ? nullptr : &w->w.particles.positions[0].x; }
+float* sphx_world_velocities(sphx_world* w) { return w->w.particles.velocities.empty() ? nullptr : &w->w.particles.velocities[0].x; }
+float* sphx_world_densities(sphx_world* w) { return w->w.particles.densities.empty() ? nullptr : w->w.particles.densities.data(); }
+float* sphx_world_boundary(sphx_world* w) {
+    return w->w.particles.boundary_particles.empty() ? nullptr : &w->w.particles.boundary_particles[0].x;
+}
+uint32_t* sphx_world_particle_ids(sphx_world* w) { return w->w.particles.particle_ids.empty() ? nullptr : w->w.particles.particle_ids.data(); }
+void sphx_world_set_particles(sphx_world* w, const float* pos_xy, const float* vel_xy, uint32_t n) {
+    auto& p = w->w.particles;
+    p.positions.resize(n);
+    p.velocities.resize(n);
+    p.densities.assign(n, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        p.positions[i] = sph::Point{pos_xy[2 * i], pos_xy[2 * i + 1]};
+        p.velocities[i] = vel_xy ? sph::Vector{vel_xy[2 * i], vel_xy[2 * i + 1]} : sph::Vector{0, 0};
+    }
+    w->w.fluid_generation++;
+}
+void sphx_world_set_boundary(sphx_world* w, const float* xy, uint32_t n) {
+    auto& b = w->w.particles.boundary_particles;
+    b.resize(n);
+    for (uint32_t i = 0; i < n; ++i) b[i] = sph::Point{xy[2 * i], xy[2 * i + 1]};
+    w->w.boundary_changed = true;
+}
+void sphx_world_set_gravity(sphx_world* w, float gx, float gy) { w->w.gravity = sph::Vector{gx, gy}; }
+
+uint64_t sphx_duration_from_secs_f32(float secs) { return sph::Duration::from_secs_f32(secs).ns; }
+float sphx_duration_as_secs_f32(uint64_t nanos) { return sph::Duration{nanos}.as_secs_f32(); }
+sphx_timer* sphx_timer_create_adaptive(uint64_t tmax, uint64_t tmin, float cfl) {
+    return new sphx_timer{sph::TimeManager::adaptive(sph::Duration{tmax}, sph::Duration{tmin}, cfl)};
+}
+sphx_timer* sphx_timer_create_fixed(uint64_t step) { return new sphx_timer{sph::TimeManager::fixed_step(sph::Duration{step})}; }
+void sphx_timer_destroy(sphx_timer* t) { delete t; }
+void sphx_timer_restart(sphx_timer* t) { t->t.restart(); }
+uint64_t sphx_timer_simulation_step_ns(const sphx_timer* t) { return t->t.simulation_step().ns; }
+uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float diameter, float vmax) { return t->t.update_simulation_step(diameter, vmax).ns; }
+uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t) { return t->t.total_simulated_time.ns; }
+uint32_t sphx_timer_num_steps(const sphx_timer* t) { return t->t.num_simulation_steps; }
+
+int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out) {
+    if (!w || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    sphx_solver* s = new sphx_solver(w->w, params);
+    if (!s->s.ok()) {
+        const int rc = s->s.last_status;
+        delete s;
+        *out = nullptr;
+        return rc;
+    }
+    *out = s;
+    return SPHX_OK;
+}
+void sphx_solver_destroy(sphx_solver* s) { delete s; }
+void sphx_solver_clear_cached_data(sphx_solver* s) { s->s.clear_cached_data(); }
+int sphx_solver_simulation_step(sphx_solver* s, sphx_world* w, sphx_timer* t, int sync_world, sphx_step_stats* out) {
+    if (!s || !w || !t) return SPHX_ERR_INVALID_ARGUMENT;
+    s->s.sync_every_step = sync_world != 0;
+    t->t.on_step_started();
+    s->s.simulation_step(w->w, t->t);
+    if (out) *out = s->s.last_stats;
+    return s->s.last_status;
+}
+int sphx_solver_sync_world(sphx_solver* s, sphx_world* w) { return s->s.sync_world(w->w); }
+sphx_ctx* sphx_solver_ctx(sphx_solver* s) { return s->s.ctx(); }
+const char* sphx_solver_last_error(const sphx_solver* s) { return s->s.last_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// sphx_internal.hpp — shared declarations of libsphx (device context, constants, launch/profiling helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sphx.h"
+
+namespace sphx {
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t MAX_NEIGHBORS = 64;  // neighborhood_search.rs:322
+constexpr uint32_t BLOCK_CELLS = 256;   // 16x16 cells per coarse block = low 8 Morton bits
+constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 threads x 16)
+
+// internal device flag bits (DevScalars::flags)
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_BLOCK_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u };
+
+// Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
+struct Consts {
+    float h;         // smoothing length = search radius = cell size
+    float radius_sq; // grid.radius * grid.radius (neighborhood_search.rs:331)
+    float cell_inv;  // 1 / cell_size (neighborhood_search.rs:475)
+    float gmin_x, gmin_y;
+    float w_hinv, w_norm, w_ngrad;  // WendlandQuinticC2::new (wendland_quintic_c2.rs:24-30)
+    float p6_hsq, p6_norm, p6_ngrad; // Poly6::new (poly6.rs:16-23)
+    float sp_h, sp_norm, sp_ngrad;  // Spiky::new (spiky.rs:16-23)
+    float mass, rho0, xsph_eps;
+    float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
+};
+
+// Two-level Morton cell grid: coarse[] is indexed by (morton >> 8) - cbase and holds the offset of the
+// block's 256 fine entries (or EMPTY); fine[] is an exclusive prefix sum of per-cell particle counts laid out in global
+// Morton order of the occupied blocks, so fine[i+1] is always the end of cell i.
+struct GridView {
+    const uint32_t* coarse;
+    const uint32_t* fine;
+    uint32_t cbase, clen;
+};
+
+struct DevScalars {
+    uint32_t vmax_sq_bits;  // max over particles of |v + a*dt|^2, as float bits (non-negative floats order like uints)
+    uint32_t flags;         // DF_*
+    uint32_t nblk[2];       // occupied coarse blocks: [0] dynamic grid, [1] static grid
+    uint32_t fine_len[2];   // nblk*256 + 1
+    double err_sum;         // residual sum of the last solver iteration
+    unsigned long long nb_entries;
+};
+
+struct Grid {
+    uint32_t* coarse = nullptr;  // clen entries (flags during build, then offsets)
+    uint32_t* fine = nullptr;    // cap_blk*256 + 1 entries
+    uint32_t cbase = 0, clen = 0, clen_cap = 0;
+    uint32_t cap_blk = 0;
+    GridView view() const { return GridView{coarse, fine, cbase, clen}; }
+};
+
+struct ProfTotals {
+    uint64_t launches = 0;
+    double ms = 0, bytes = 0;
+};
+struct ProfPending {
+    const char* name;
+    double bytes;
+    hipEvent_t a, b;
+};
+
+}  // namespace sphx
+
+struct sphx_ctx {
+    sphx_params P;
+    sphx::Consts K;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    uint32_t N = 0, capN = 0;  // fluid particles
+    uint32_t B = 0, capB = 0;  // boundary particles
+    uint32_t cached_n = 0;     // alpha_values.len() of the reference (dfsph.rs:419)
+    bool uploaded = false, boundary_changed = true, in_step = false;
+    uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
+    float step_dt_prev = 0, step_vmax = 0;
+    uint32_t step_flags = 0;
+
+    // particle arrays (device).  *2 = gather destinations (ping-pong).
+    float2 *pos = nullptr, *vel = nullptr, *vstar = nullptr, *accel = nullptr;
+    float2 *pos2 = nullptr, *vel2 = nullptr, *vstar2 = nullptr;
+    float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr, *err_buf = nullptr;
+    uint32_t *pid = nullptr, *pid2 = nullptr;
+    uint32_t *key = nullptr, *slot = nullptr, *order = nullptr;  // grid-build scratch, sized for max(N, B)
+    uint32_t idx_cap = 0;
+    // boundary
+    float2 *bpos = nullptr, *bpos2 = nullptr;
+    uint32_t *bid = nullptr, *bid2 = nullptr;
+    std::vector<float> h_boundary;  // host copy (xy) in caller order, for domain computation
+    // grids
+    sphx::Grid gdyn, gstat;
+    uint32_t dom_x0 = 0, dom_y0 = 0, dom_x1 = 0, dom_y1 = 0;  // cell-space domain box the coarse tables cover
+    bool have_fluid_bbox = false, have_boundary_bbox = false;
+    uint32_t fb[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};  // fluid / boundary cell bboxes (x0,y0,x1,y1)
+    // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
+    uint32_t* nb_list = nullptr;
+    uint32_t* nb_counts = nullptr;  // (count_total << 16) | count_dynamic
+    // scan scratch
+    uint32_t* scan_partials = nullptr;
+    uint32_t scan_partials_cap = 0;
+    double* red_partials = nullptr;
+    uint32_t red_partials_cap = 0;
+    // scalars
+    sphx::DevScalars* d_scal = nullptr;
+    sphx::DevScalars* h_scal = nullptr;  // pinned
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<sphx::ProfPending> prof_pending;
+    std::map<std::string, sphx::ProfTotals> prof_totals;
+
+    int fail(int code, const char* what, const char* detail = nullptr) {
+        err = what;
+        if (detail) {
+            err += ": ";
+            err += detail;
+        }
+        return code;
+    }
+};
