@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/sec of the 2D DFSPH dam-break (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one Solver::simulation_step (dfsph.rs:414-525) of the dam-break scene of main.rs:177-196 scaled to ~P
+particles per GPU, driven exactly like the drop-in shim would drive it: sphx_step_begin -> host TimeManager CFL law ->
+sphx_step_finish, adaptive timer from t = 0.  Inputs are uploaded before the timed region starts (device resident).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv):
+    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step."""
+    return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar)
+
+
+def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
+    """The oracle's OpenMP build (the reference's Rayon loops restated; 'port') timed on this host's cores."""
+    from oracle.oracle import Oracle, lib
+
+    L = lib(omp=True)
+    cores = L.orc_get_max_threads()
+    o = Oracle(omp=True)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    o.dfsph_step()  # includes the warm-up block, like the GPU warm-up steps
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < max_steps:
+        o.dfsph_step()
+        steps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {
+        "value": len(pos) * steps / el,
+        "unit": "particle-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} DFSPH steps of the same {len(pos)}-particle dam-break after 1 warm-up step, "
+                  f"C++/OpenMP restatement of yasph2d's Rayon path (not the Rust binary), {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+
+    import yasph2d_amd as y
+
+    scale = float(np.sqrt(args.particles / 4050.0))
+    w = y.FluidParticleWorld()
+    w.reset_fluid(scale)
+    pos, boundary = w.positions, w.boundary_particles
+    n = len(pos)
+
+    ctx = y.SphxContext(y.default_params(device=local_rank))
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
+
+    def one_step():
+        vmax = ctx.step_begin(timer.simulation_step())
+        dt_ns = timer.update_simulation_step(diam, vmax)
+        return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+
+    stats = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats.append(one_step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    Id = float(np.mean([s["density_iterations"] for s in stats]))
+    Iv = float(np.mean([s["divergence_iterations"] for s in stats]))
+    Wd = float(np.mean([s["warmstart_density"] for s in stats]))
+    Wv = float(np.mean([s["warmstart_divergence"] for s in stats]))
+    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n
+
+    roof = None
+    if not args.no_roofline:
+        # Second pass of the same loop with every launch bracketed by hipEvents on the context's stream (the events would
+        # perturb the host-driven timed region above, so they are kept out of it).  Dominant kernel = largest total time.
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(max(10, min(args.steps, 50))):
+            one_step()
+        ctx.profile_enable(False)
+        prof = ctx.profile_get()
+        name, rec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        avg_ms = rec["total_ms"] / rec["launches"]
+        ach = rec["bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
+        roof = {
+            "bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["launches"],
+            "algorithmic_bytes_per_launch": rec["bytes"] / rec["launches"],
+            "per_kernel_ms_per_step": {k: v["total_ms"] / max(10, min(args.steps, 50)) for k, v in sorted(prof.items())},
+        }
+
+    if rank == 0:
+        value = n * args.steps * world / elapsed
+        bstep = bytes_per_particle_step(kbar, Id, Iv, Wd, Wv)
+        out = {
+            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"DFSPH 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n} fluid + {len(boundary)} boundary particles per GPU, "
+                            f"adaptive CFL timer from t=0, two-phase step through the C ABI",
+                "particles_per_gpu": n,
+                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (spatial tiles + RCCL halo: not yet implemented)",
+                "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
+            },
+            "step_model": {"bytes_per_particle_step": bstep,
+                           "achieved_GBs_whole_step": bstep * n * args.steps / elapsed / 1e9,
+                           "frac_of_hbm_peak_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+        }
+        if roof:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(pos, boundary)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,13 +44,19 @@ struct GridView {
     uint32_t cbase, clen;
 };
 
+constexpr uint32_t STRIPES = 32;  // same-address atomics serialise in L2: reductions are striped over 32 cache lines
+struct alignas(128) Stripe {
+    unsigned long long nb_entries;  // partial sum of count_total (stats only)
+    uint32_t vmax_sq_bits;          // partial max of |v + a*dt|^2 as float bits (non-negative floats order like uints)
+    uint32_t pad[29];
+};
 struct DevScalars {
-    uint32_t vmax_sq_bits;  // max over particles of |v + a*dt|^2, as float bits (non-negative floats order like uints)
     uint32_t flags;         // DF_*
     uint32_t nblk[2];       // occupied coarse blocks: [0] dynamic grid, [1] static grid
     uint32_t fine_len[2];   // nblk*256 + 1
+    uint32_t pad;
     double err_sum;         // residual sum of the last solver iteration
-    unsigned long long nb_entries;
+    Stripe stripe[STRIPES];
 };
 
 struct Grid {

@@ -370,11 +370,17 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         counts[i] = (ct << 16) | cd;
         if (flags) atomicOr(&scal->flags, flags);
     }
-    // total number of list entries (stats only)
+    // total number of list entries (stats only): block reduce, one striped atomic per workgroup
     unsigned long long s = ct;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&scal->nb_entries, s);
+    __shared__ unsigned long long ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];
+        if (t) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -453,11 +459,23 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float2* __restrict__ 
         const float px = vi.x + ax * dt, py = vi.y + ay * dt;
         vsq = px * px + py * py;
     }
-    // exact max: non-negative floats order like their bit patterns
+    // exact max: non-negative floats order like their bit patterns.  wave -> block -> one striped atomic per workgroup,
+    // skipped when the stripe already holds a value at least as large.
     uint32_t b = __float_as_uint(vsq);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
-    if ((threadIdx.x & 63) == 0 && b) atomicMax(&scal->vmax_sq_bits, b);
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        uint32_t* dst = &scal->stripe[blockIdx.x % STRIPES].vmax_sq_bits;
+        if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+    }
+}
+
+__global__ void k_clear_vmax(DevScalars* scal) {
+    if (threadIdx.x < STRIPES) scal->stripe[threadIdx.x].vmax_sq_bits = 0;
 }
 
 // a12: dfsph.rs:484-492
