@@ -18,6 +18,8 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_NEIGHBORS = 64;  // neighborhood_search.rs:322
 constexpr uint32_t BLOCK_CELLS = 256;   // 16x16 cells per coarse block = low 8 Morton bits
 constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 threads x 16)
+constexpr uint32_t STAGE_ROWS = 32;     // neighbour rows staged in LDS per wave before the coalesced row store
+constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
 enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_BLOCK_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u };
@@ -28,14 +30,14 @@ struct Consts {
     float radius_sq; // grid.radius * grid.radius (neighborhood_search.rs:331)
     float cell_inv;  // 1 / cell_size (neighborhood_search.rs:475)
     float gmin_x, gmin_y;
-    float w_hinv, w_norm, w_ngrad;  // WendlandQuinticC2::new (wendland_quintic_c2.rs:24-30)
+    float w_hinv, w_norm, w_ngrad;   // WendlandQuinticC2::new (wendland_quintic_c2.rs:24-30)
     float p6_hsq, p6_norm, p6_ngrad; // Poly6::new (poly6.rs:16-23)
-    float sp_h, sp_norm, sp_ngrad;  // Spiky::new (spiky.rs:16-23)
+    float sp_h, sp_norm, sp_ngrad;   // Spiky::new (spiky.rs:16-23)
     float mass, rho0, xsph_eps;
     float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
 };
 
-// Two-level Morton cell grid (see DESIGN.md §3): coarse[] is indexed by (morton >> 8) - cbase and holds the offset of the
+// Two-level Morton cell grid (DESIGN.md §3): coarse[] is indexed by (morton >> 8) - cbase and holds the offset of the
 // block's 256 fine entries (or EMPTY); fine[] is an exclusive prefix sum of per-cell particle counts laid out in global
 // Morton order of the occupied blocks, so fine[i+1] is always the end of cell i.
 struct GridView {
@@ -44,23 +46,32 @@ struct GridView {
     uint32_t cbase, clen;
 };
 
-constexpr uint32_t STRIPES = 32;  // same-address atomics serialise in L2: reductions are striped over 32 cache lines
 struct alignas(128) Stripe {
-    unsigned long long nb_entries;  // partial sum of count_total (stats only)
-    uint32_t vmax_sq_bits;          // partial max of |v + a*dt|^2 as float bits (non-negative floats order like uints)
+    unsigned long long nb_entries;  // partial sum of count_total over ALL builds so far (stats only; the host takes differences)
+    uint32_t ticket;                // first-level arrival counter of the last-block reductions
     uint32_t pad[29];
 };
 struct DevScalars {
-    uint32_t flags;         // DF_*
-    uint32_t nblk[2];       // occupied coarse blocks: [0] dynamic grid, [1] static grid
-    uint32_t fine_len[2];   // nblk*256 + 1
-    uint32_t pad;
-    double err_sum;         // residual sum of the last solver iteration
+    uint32_t flags;        // DF_*
+    uint32_t nblk[2];      // occupied coarse blocks: [0] dynamic grid, [1] static grid
+    uint32_t fine_len[2];  // nblk*256 + 1
+    uint32_t ticket;       // second-level arrival counter (one arrival per stripe); reset by the last arriver
     Stripe stripe[STRIPES];
+};
+
+// Pinned, host-coherent memory the device publishes step scalars into (no D2H copy, no stream sync on the fast path).
+struct Mailbox {
+    volatile uint32_t seq;  // written last (system scope); the host waits for the value it passed to the kernel
+    uint32_t flags;
+    uint32_t vmax_sq_bits;  // max |v + a*dt|^2 as float bits
+    uint32_t pad;
+    double err_sum;         // residual sum of the last compute_error launch
+    unsigned long long nb_entries;
 };
 
 struct Grid {
     uint32_t* coarse = nullptr;  // clen entries (flags during build, then offsets)
+    uint32_t* coarse_next = nullptr;  // all-zero flag buffer for the next build (cleared by this build's scan, then swapped)
     uint32_t* fine = nullptr;    // cap_blk*256 + 1 entries
     uint32_t cbase = 0, clen = 0, clen_cap = 0;
     uint32_t cap_blk = 0;
@@ -89,22 +100,26 @@ struct sphx_ctx {
     uint32_t N = 0, capN = 0;  // fluid particles
     uint32_t B = 0, capB = 0;  // boundary particles
     uint32_t cached_n = 0;     // alpha_values.len() of the reference (dfsph.rs:419)
-    bool uploaded = false, boundary_changed = true, in_step = false;
+    bool uploaded = false, boundary_changed = true, tails_dirty = true, in_step = false;
     uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
     float step_dt_prev = 0, step_vmax = 0;
     uint32_t step_flags = 0;
 
-    // particle arrays (device).  *2 = gather destinations (ping-pong).
-    float2 *pos = nullptr, *vel = nullptr, *vstar = nullptr, *accel = nullptr;
-    float2 *pos2 = nullptr, *vel2 = nullptr, *vstar2 = nullptr;
-    float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr, *err_buf = nullptr;
+    // Particle state (device, Morton cell order).  Arrays marked [N|B] hold the fluid particles in [0, N) and the sorted
+    // boundary particles as a tail at offset soff() = capN, so a neighbour index j (dynamic) or soff()+j (static) addresses
+    // one array and the traversal loops need no dynamic/static branch.
+    float2 *posA = nullptr, *posA2 = nullptr;  // [N|B] positions (compact copy for the candidate scan)
+    float4 *PV = nullptr, *PV2 = nullptr;      // [N|B] {pos.x, pos.y, v.x, v.y}: v = velocity, after predict = predicted velocity
+    float4* PK = nullptr;                      // [N|B] {pos.x, pos.y, k = err*alpha, err}: written by compute_error, gathered by correct
+    float2* accel = nullptr;                   // [N]
+    float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr;  // [N]
     uint32_t *pid = nullptr, *pid2 = nullptr;
     uint32_t *key = nullptr, *slot = nullptr, *order = nullptr;  // grid-build scratch, sized for max(N, B)
     uint32_t idx_cap = 0;
-    // boundary
+    uint32_t soff() const { return capN; }
+    // boundary (own arrays for the one-off static grid build)
     float2 *bpos = nullptr, *bpos2 = nullptr;
     uint32_t *bid = nullptr, *bid2 = nullptr;
-    std::vector<float> h_boundary;  // host copy (xy) in caller order, for domain computation
     // grids
     sphx::Grid gdyn, gstat;
     uint32_t dom_x0 = 0, dom_y0 = 0, dom_x1 = 0, dom_y1 = 0;  // cell-space domain box the coarse tables cover
@@ -113,14 +128,16 @@ struct sphx_ctx {
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
     uint32_t* nb_counts = nullptr;  // (count_total << 16) | count_dynamic
-    // scan scratch
+    // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;
-    double* red_partials = nullptr;
-    uint32_t red_partials_cap = 0;
+    double* red_partials = nullptr;  // one slot per workgroup (also reinterpreted as u32 for the max reduction)
     // scalars
     sphx::DevScalars* d_scal = nullptr;
-    sphx::DevScalars* h_scal = nullptr;  // pinned
+    sphx::Mailbox* mbox = nullptr;      // pinned host memory
+    sphx::Mailbox* mbox_dev = nullptr;  // its device address
+    uint32_t seq = 0;
+    unsigned long long nb_cum = 0, nb_last = 0;  // cumulative neighbour-entry counter seen so far / entries of the last build
 
     // profiling
     bool profiling = false;

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
 }
 
 // single workgroup: exclusive scan of the tile partials; writes the grand total
+// which >= 0 (coarse pass): the total is the number of occupied blocks -> clamp to cap_blk, publish nblk and fine_len = nblk*256+1
 __global__ __launch_bounds__(1024) void k_scan_partials(uint32_t* __restrict__ partials, uint32_t len, const uint32_t* __restrict__ d_len,
-                                                         uint32_t* __restrict__ d_total) {
+                                                         DevScalars* __restrict__ scal, int which, uint32_t cap_blk) {
     if (d_len) len = *d_len;
     const uint32_t ntiles = (len + SCAN_TILE - 1) / SCAN_TILE;
     __shared__ uint32_t wsum[16];
@@ -142,7 +143,12 @@ __global__ __launch_bounds__(1024) void k_scan_partials(uint32_t* __restrict__ p
         if (threadIdx.x == 1023) carry_s = base + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && d_total) *d_total = carry_s;
+    if (threadIdx.x == 0 && which >= 0) {
+        uint32_t nb = carry_s;
+        if (nb > cap_blk) nb = cap_blk;
+        scal->nblk[which] = nb;
+        scal->fine_len[which] = nb * BLOCK_CELLS + 1;
+    }
 }
 
 // MODE 0: out[i] = exclusive prefix.  MODE 1 (coarse table): in[i] is a 0/1 flag, out[i] = flag ? prefix*256 : EMPTY,
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_scan_partials(uint32_t* __restrict__ p
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t len,
                                                      const uint32_t* __restrict__ d_len, const uint32_t* __restrict__ partials, uint32_t cap_blk,
-                                                     DevScalars* __restrict__ scal) {
+                                                     DevScalars* __restrict__ scal, uint32_t* __restrict__ zero_out) {
     if (d_len) len = *d_len;
     const uint32_t base = blockIdx.x * SCAN_TILE;
     if (base >= len) return;
@@ -180,18 +186,62 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
                         atomicOr(&scal->flags, DF_BLOCK_CAP);
                 }
                 out[idx] = o;
+                if (zero_out) zero_out[idx] = 0;  // flag buffer of the NEXT build
             }
         }
         run += v[k];
     }
 }
 
-// after the coarse scan: clamp nblk to capacity, publish fine_len = nblk*256+1
-__global__ void k_grid_finish_coarse(DevScalars* scal, int which, uint32_t cap_blk) {
-    uint32_t n = scal->nblk[which];
-    if (n > cap_blk) n = cap_blk;
-    scal->nblk[which] = n;
-    scal->fine_len[which] = n * BLOCK_CELLS + 1;
+// ------------------------------------------------------------------------------------------------------------------
+// last-block reductions: every workgroup stores one partial with a write-through (agent-scope) store, takes a ticket, and
+// the last arriver reduces all partials in a FIXED order and publishes the result to the pinned host mailbox.
+// (cdna_hip_programming.md Guideline 16: sc1 stores -> s_waitcnt vmcnt(0) -> relaxed agent fetch_add; reducer reads with
+// agent-scope loads.)  Deterministic: the order of the final reduction depends only on the grid size.
+// ------------------------------------------------------------------------------------------------------------------
+// Two-level arrival: a single counter would serialise ~4000 returning atomics (~12 ns each); each workgroup arrives at one
+// of STRIPES counters and only the last arriver of a stripe arrives at the top counter.
+__device__ __forceinline__ bool arrive_is_last(DevScalars* scal) {  // call from ONE thread after its partial store
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t s = blockIdx.x % STRIPES;
+    const uint32_t expect = gridDim.x / STRIPES + (s < gridDim.x % STRIPES ? 1u : 0u);
+    const uint32_t t = __hip_atomic_fetch_add(&scal->stripe[s].ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != expect - 1) return false;
+    __hip_atomic_store(&scal->stripe[s].ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nstripes = gridDim.x < STRIPES ? gridDim.x : STRIPES;
+    const uint32_t t2 = __hip_atomic_fetch_add(&scal->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t2 == nstripes - 1;
+}
+__device__ __forceinline__ void publish_common(DevScalars* scal, Mailbox* mb, uint32_t seq) {  // one thread of the last block
+    unsigned long long nb = 0;
+    for (uint32_t k = 0; k < STRIPES; ++k) nb += __hip_atomic_load(&scal->stripe[k].nb_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mb->nb_entries = nb;
+    mb->flags = __hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// block-wide f64 sum in a fixed tree (lane -> wave -> 4 waves); result valid in thread 0
+__device__ __forceinline__ double block_sum_f64(double s) {
+    __shared__ double ws[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double t = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t b) {
+    __shared__ uint32_t wm[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
+    __syncthreads();
+    const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    __syncthreads();
+    return m;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -214,24 +264,60 @@ __global__ __launch_bounds__(256) void k_cell_key(const float2* __restrict__ pos
         atomicOr(&scal->flags, DF_OUT_OF_DOMAIN);
 }
 
+// a17 + a1 fused: advect (dfsph.rs:499-510) and the cell key of the new position in one pass
+__global__ __launch_bounds__(256) void k_advect_key(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t n, float dt, Consts K,
+                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ coarse_flags, uint32_t cbase,
+                                                     uint32_t clen, DevScalars* __restrict__ scal) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 pv = PV[i];
+    pv.x = pv.x + pv.z * dt;
+    pv.y = pv.y + pv.w * dt;
+    PV[i] = pv;
+    const float2 p = make_float2(pv.x, pv.y);
+    posA[i] = p;
+    uint32_t cx, cy;
+    cell_of(K, p, cx, cy);
+    const uint32_t k = morton2(cx, cy);
+    key[i] = k;
+    const uint32_t c = (k >> 8) - cbase;
+    if (c < clen)
+        coarse_flags[c] = 1;
+    else
+        atomicOr(&scal->flags, DF_OUT_OF_DOMAIN);
+}
+
 __global__ __launch_bounds__(256) void k_clear_fine(uint32_t* __restrict__ fine, const uint32_t* __restrict__ d_len) {
     const uint32_t len = *d_len;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) fine[i] = 0;
 }
 
-// per-cell histogram; the value returned by the atomic is the particle's (arbitrary) arrival slot inside its cell
+// Per-cell histogram.  Particles arrive almost sorted (they were in cell order one step ago), so equal cells sit in adjacent
+// lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.  The value returned is an arbitrary
+// arrival slot inside the cell; k_rank_gather restores the stable order.
 __global__ __launch_bounds__(256) void k_cell_count(const uint32_t* __restrict__ key, uint32_t n, GridView g, uint32_t* __restrict__ fine,
                                                      uint32_t* __restrict__ slot) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = key[i];
-    const uint32_t c = (k >> 8) - g.cbase;
-    uint32_t s = EMPTY;
-    if (c < g.clen) {
-        const uint32_t off = g.coarse[c];
-        if (off != EMPTY) s = atomicAdd(&fine[off + (k & 255u)], 1u);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t idx = EMPTY;
+    if (i < n) {
+        const uint32_t k = key[i];
+        const uint32_t c = (k >> 8) - g.cbase;
+        if (c < g.clen) {
+            const uint32_t off = g.coarse[c];
+            if (off != EMPTY) idx = off + (k & 255u);
+        }
     }
-    slot[i] = s;
+    const uint32_t prev = __shfl_up(idx, 1, 64);
+    const bool head = (lane == 0) || (idx != prev);
+    const unsigned long long mask = __ballot(head);
+    const uint32_t start = 63u - (uint32_t)__clzll(mask & (~0ull >> (63u - lane)));
+    const unsigned long long rest = (lane == 63) ? 0ull : (mask >> (lane + 1));
+    const uint32_t end = rest ? lane + (uint32_t)__ffsll((long long)rest) : 64u;
+    uint32_t base = 0;
+    if (head && idx != EMPTY) base = atomicAdd(&fine[idx], end - lane);
+    base = __shfl(base, start, 64);
+    if (i < n) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
 }
 
 // order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order)
@@ -248,8 +334,10 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ke
 }
 
 struct GatherArgs {
-    const float2* v_in[3];
-    float2* v_out[3];
+    const float2* pos_in;  // boundary build: plain positions
+    float2* pos_out;       // fluid build: receives PV.xy
+    const float4* pv_in;
+    float4* pv_out;
     const float* r_in;
     float* r_out;
     const uint32_t* u_in;
@@ -271,9 +359,13 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     for (uint32_t q = s; q < e; ++q) rank += (order[q] < i) ? 1u : 0u;
     const uint32_t dst = s + rank;
     if (dst >= n) return;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (a.v_in[t]) a.v_out[t][dst] = a.v_in[t][i];
+    if (a.pv_in) {
+        const float4 pv = a.pv_in[i];
+        a.pv_out[dst] = pv;
+        a.pos_out[dst] = make_float2(pv.x, pv.y);
+    } else {
+        a.pos_out[dst] = a.pos_in[i];
+    }
     if (a.r_in) a.r_out[dst] = a.r_in[i];
     if (a.u_in) a.u_out[dst] = a.u_in[i];
 }
@@ -286,10 +378,41 @@ __global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ a, uint32_
     const uint32_t i = from + blockIdx.x * 256 + threadIdx.x;
     if (i < n) a[i] = v;
 }
+// upload: PV[i] = {pos, vel}
+__global__ __launch_bounds__(256) void k_pack_pv(const float2* __restrict__ pos, const float2* __restrict__ vel, uint32_t n, float4* __restrict__ PV) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = pos[i], v = vel[i];
+    PV[i] = make_float4(p.x, p.y, v.x, v.y);
+}
+// download: velocities out of PV
+__global__ __launch_bounds__(256) void k_unpack_vel(const float4* __restrict__ PV, uint32_t n, float2* __restrict__ vel) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 pv = PV[i];
+    vel[i] = make_float2(pv.z, pv.w);
+}
+// boundary tails of the [N|B] arrays: {bpos, 0, 0}
+__global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ bpos, uint32_t nb, uint32_t soff, float2* __restrict__ posA,
+                                                     float2* __restrict__ posA2, float4* __restrict__ PV, float4* __restrict__ PV2,
+                                                     float4* __restrict__ PK) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb) return;
+    const float2 p = bpos[j];
+    const float4 r = make_float4(p.x, p.y, 0.0f, 0.0f);
+    posA[soff + j] = p;
+    posA2[soff + j] = p;
+    PV[soff + j] = r;
+    PV2[soff + j] = r;
+    PK[soff + j] = r;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
-// a5+a6: neighbour lists.  neighborhood_search.rs:312-397 — candidates = particles of the 3x3 cell box visited in ascending
-// sorted index (= ascending Morton code of the 9 cells), accepted iff 1e-10 < d^2 <= h^2, dynamic first then static, cap 64.
+// a5+a6 (+a8+a9 fused): neighbour lists.  neighborhood_search.rs:312-397 — candidates = particles of the 3x3 cell box visited
+// in ascending sorted index (= ascending Morton code of the 9 cells), accepted iff 1e-10 < d^2 <= h^2, dynamic first then
+// static, cap 64.  FUSE additionally accumulates the density (fluidparticleworld.rs:197-231) and the alpha factor
+// (dfsph.rs:68-97) while the neighbours are found — same neighbours, same order, so the sums are bit-identical to a separate
+// traversal of the finished list (the reference's own `todo: fuse`, dfsph.rs:514).
 // ------------------------------------------------------------------------------------------------------------------
 #define SPHX_CE(a, b)                      \
     {                                      \
@@ -307,13 +430,38 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
     SPHX_CE(c2, c3)
 }
 
-__global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict__ pos, uint32_t n, Consts K, GridView gd,
-                                                         const float2* __restrict__ bpos, GridView gs, uint32_t* __restrict__ list,
-                                                         uint32_t* __restrict__ counts, DevScalars* __restrict__ scal) {
+// particle ranges of 9 (ascending) cell codes; the coarse entry is re-read only when the 16x16 block changes
+__device__ __forceinline__ void lookup9(const GridView& g, const uint32_t (&c)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
+    uint32_t pblk = 0xFFFFFFFFu, poff = EMPTY;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t blk = (c[t] >> 8) - g.cbase;
+        if (blk != pblk) {
+            poff = (blk < g.clen) ? g.coarse[blk] : EMPTY;
+            pblk = blk;
+        }
+        uint32_t a = 0, b = 0;
+        if (poff != EMPTY && c[t] != 0xFFFFFFFFu) {
+            const uint32_t idx = poff + (c[t] & 255u);
+            a = g.fine[idx];
+            b = g.fine[idx + 1];
+        }
+        s[t] = a;
+        e[t] = b;
+    }
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
+                                                         GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
+                                                         float* __restrict__ density, float* __restrict__ alpha,
+                                                         DevScalars* __restrict__ scal) {
+    __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..31 of each wave, written out as whole 256-byte rows
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t ct = 0;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t cd = 0, ct = 0;
     if (i < n) {
-        const float2 pi = pos[i];
+        const float2 pi = posA[i];
         uint32_t cx, cy;
         cell_of(K, pi, cx, cy);
         // Morton codes of the 3x3 box; cells outside the u16 range get the (never occupied) code 0xFFFFFFFF.
@@ -326,56 +474,75 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                 c[(dy + 1) * 3 + (dx + 1)] = (x < 65535u && y < 65535u) ? morton2(x, y) : 0xFFFFFFFFu;
             }
         sort9(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
-        const size_t lbase = ell_index(i, 0);
-        uint32_t cd = 0;
         uint32_t flags = 0;
+        float rho = 0.0f, gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
+        if (FUSE) rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
+
+        auto accept = [&](uint32_t j, float dx, float dy, float d2) {
+            if (ct < STAGE_ROWS)
+                tile[w][ct][lane] = j;
+            else
+                list[ell_index(i, ct)] = j;
+            ct += 1;
+            if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;
+            if (FUSE) {
+                const float r = sqrtf(d2);
+                const float q = fminf(r * K.w_hinv, 1.0f);
+                const float omq = 1.0f - q;
+                const float omq_sq = omq * omq;
+                rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
+                const float sg = K.w_ngrad * omq * omq * omq;
+                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+                gsx += gx;
+                gsy += gy;
+                gss += gx * gx + gy * gy;
+            }
+        };
+
+        uint32_t s[9], e[9];
+        lookup9(gd, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            uint32_t s, e;
-            if (c[t] != 0xFFFFFFFFu && grid_range(gd, c[t], s, e)) {
-                for (uint32_t j = s; j < e; ++j) {
-                    const float2 pj = pos[j];
-                    const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-                    const float d2 = dx * dx + dy * dy;
-                    if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
-                        if (cd < MAX_NEIGHBORS) {
-                            list[lbase + (size_t)cd * 64] = j;
-                            cd += 1;
-                            if (cd == MAX_NEIGHBORS) flags |= DF_NB_CAP;
-                        }
-                    }
-                }
+            for (uint32_t j = s[t]; j < e[t]; ++j) {
+                const float2 pj = posA[j];
+                const float dx = pj.x - pi.x, dy = pj.y - pi.y;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 <= K.radius_sq && d2 > 1.0e-10f && ct < MAX_NEIGHBORS) accept(j, dx, dy, d2);
             }
         }
-        ct = cd;
+        cd = ct;
+        lookup9(gs, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            uint32_t s, e;
-            if (c[t] != 0xFFFFFFFFu && grid_range(gs, c[t], s, e)) {
-                for (uint32_t j = s; j < e; ++j) {
-                    const float2 pj = bpos[j];
-                    const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-                    const float d2 = dx * dx + dy * dy;
-                    if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
-                        if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
-                        if (ct < MAX_NEIGHBORS) {
-                            list[lbase + (size_t)ct * 64] = j;
-                            ct += 1;
-                            if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;
-                        }
-                    }
+            for (uint32_t j = s[t]; j < e[t]; ++j) {
+                const float2 pj = posA[soff + j];
+                const float dx = pj.x - pi.x, dy = pj.y - pi.y;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
+                    if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
+                    if (ct < MAX_NEIGHBORS) accept(j, dx, dy, d2);
                 }
             }
         }
         counts[i] = (ct << 16) | cd;
+        if (FUSE) {
+            density[i] = fmaxf(rho, K.rho0);                                    // fluidparticleworld.rs:229
+            alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);      // dfsph.rs:94
+        }
         if (flags) atomicOr(&scal->flags, flags);
     }
-    // total number of list entries (stats only): block reduce, one striped atomic per workgroup
-    unsigned long long s = ct;
+    // staged rows -> global, one coalesced 256-byte row per store (lanes past their own count write don't-care values)
+    uint32_t m = min(ct, STAGE_ROWS);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    const size_t row0 = (size_t)(i >> 6) * 64;
+    for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = tile[w][k][lane];
+    // total number of list entries (stats only): block reduce, one striped atomic per workgroup
+    unsigned long long tot = ct;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_down(tot, d, 64);
     __shared__ unsigned long long ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    if (lane == 0) ws[w] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];
@@ -384,16 +551,20 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// a8 + a9: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97), one traversal
+// neighbour traversal: loads are issued in batches of NB_BATCH (indices, then records) so several gathers are in flight per
+// lane; the accumulation stays sequential in list order.
 // ------------------------------------------------------------------------------------------------------------------
-// KIND: 0 Wendland, 1 Poly6, 2 Spiky (the kinds benches/benchmarks/update_densities.rs drives)
+#define NB_BATCH 4
+
+// a8 / a9 stand-alone (the pieces benches/ and the warm-up drive): densities and alpha factors from a finished list
+// KIND: 0 Wendland, 1 Poly6, 2 Spiky
 template <int KIND, bool DENSITY, bool ALPHA>
-__global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ pos, const float2* __restrict__ bpos, uint32_t n, Consts K,
+__global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
                                                         float* __restrict__ density, float* __restrict__ alpha) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float2 ri = pos[i];
+    const float2 ri = posA[i];
     const uint32_t c = counts[i];
     const uint32_t cd = c & 0xffffu, ct = c >> 16;
     const uint32_t* lp = list + ell_index(i, 0);
@@ -404,27 +575,36 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
         if (KIND == 2) rho = spiky_eval(K, 0.0f) * K.mass;
     }
     float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-    for (uint32_t k = 0; k < ct; ++k) {
-        const uint32_t j = lp[(size_t)k * 64];
-        const float2 rj = (k < cd) ? pos[j] : bpos[j];
-        const float dx = rj.x - ri.x, dy = rj.y - ri.y;
-        const float r_sq = dx * dx + dy * dy;
-        const float r = sqrtf(r_sq);
-        if (DENSITY) {
-            float w;
-            if (KIND == 0) w = wendland_eval(K, r);
-            if (KIND == 1) w = poly6_eval(K, r_sq);
-            if (KIND == 2) w = spiky_eval(K, r);
-            rho += w * K.mass;
-        }
-        if (ALPHA) {
-            const float q = fminf(r * K.w_hinv, 1.0f);
-            const float omq = 1.0f - q;
-            const float s = K.w_ngrad * omq * omq * omq;
-            const float gx = (s * dx) * K.mass, gy = (s * dy) * K.mass;
-            gsx += gx;
-            gsy += gy;
-            gss += gx * gx + gy * gy;
+    for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
+        uint32_t j[NB_BATCH];
+        float2 rj[NB_BATCH];
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) rj[u] = posA[(k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u]];
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) {
+            if (k0 + u < ct) {
+                const float dx = rj[u].x - ri.x, dy = rj[u].y - ri.y;
+                const float r_sq = dx * dx + dy * dy;
+                const float r = sqrtf(r_sq);
+                if (DENSITY) {
+                    float wv;
+                    if (KIND == 0) wv = wendland_eval(K, r);
+                    if (KIND == 1) wv = poly6_eval(K, r_sq);
+                    if (KIND == 2) wv = spiky_eval(K, r);
+                    rho += wv * K.mass;
+                }
+                if (ALPHA) {
+                    const float q = fminf(r * K.w_hinv, 1.0f);
+                    const float omq = 1.0f - q;
+                    const float sg = K.w_ngrad * omq * omq * omq;
+                    const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+                    gsx += gx;
+                    gsy += gy;
+                    gss += gx * gx + gy * gy;
+                }
+            }
         }
     }
     if (DENSITY) density[i] = fmaxf(rho, K.rho0);                                  // fluidparticleworld.rs:229
@@ -434,96 +614,110 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_nonpressure(const float2* __restrict__ pos, const float2* __restrict__ vel,
-                                                      const float* __restrict__ density, uint32_t n, Consts K, float dt,
-                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
-                                                      float2* __restrict__ accel, DevScalars* __restrict__ scal) {
+__global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
+                                                      float dt, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
+                                                      float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
+                                                      Mailbox* __restrict__ mb, uint32_t seq) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float vsq = 0.0f;
     if (i < n) {
-        const float2 ri = pos[i], vi = vel[i];
+        const float4 pvi = PV[i];
         const uint32_t cd = counts[i] & 0xffffu;
         const uint32_t* lp = list + ell_index(i, 0);
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
-        for (uint32_t k = 0; k < cd; ++k) {
-            const uint32_t j = lp[(size_t)k * 64];
-            const float2 rj = pos[j], vj = vel[j];
-            const float dx = rj.x - ri.x, dy = rj.y - ri.y;
-            const float r_sq = dx * dx + dy * dy;
-            const float f = em * poly6_eval(K, r_sq) / (density[j] * dt);
-            ax += f * (vj.x - vi.x);
-            ay += f * (vj.y - vi.y);
+        for (uint32_t k0 = 0; k0 < cd; k0 += NB_BATCH) {
+            uint32_t j[NB_BATCH];
+            float4 r[NB_BATCH];
+            float rho[NB_BATCH];
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < cd) ? lp[(size_t)(k0 + u) * 64] : i;
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) {
+                r[u] = PV[j[u]];
+                rho[u] = density[j[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) {
+                if (k0 + u < cd) {
+                    const float dx = r[u].x - pvi.x, dy = r[u].y - pvi.y;
+                    const float r_sq = dx * dx + dy * dy;
+                    const float f = em * poly6_eval(K, r_sq) / (rho[u] * dt);
+                    ax += f * (r[u].z - pvi.z);
+                    ay += f * (r[u].w - pvi.w);
+                }
+            }
         }
         accel[i] = make_float2(ax, ay);
-        const float px = vi.x + ax * dt, py = vi.y + ay * dt;
+        const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = px * px + py * py;
     }
-    // exact max: non-negative floats order like their bit patterns.  wave -> block -> one striped atomic per workgroup,
-    // skipped when the stripe already holds a value at least as large.
-    uint32_t b = __float_as_uint(vsq);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
-    __shared__ uint32_t wm[4];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
-    __syncthreads();
+    // exact max: non-negative floats order like their bit patterns
+    const uint32_t m = block_max_u32(__float_as_uint(vsq));
+    __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
-        const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-        uint32_t* dst = &scal->stripe[blockIdx.x % STRIPES].vmax_sq_bits;
-        if (m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+        __hip_atomic_store(&partials[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = arrive_is_last(scal) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_s) {
+        uint32_t b = 0;
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) b = max(b, __hip_atomic_load(&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b = block_max_u32(b);
+        if (threadIdx.x == 0) {
+            mb->vmax_sq_bits = b;
+            publish_common(scal, mb, seq);
+        }
     }
 }
 
-__global__ void k_clear_vmax(DevScalars* scal) {
-    if (threadIdx.x < STRIPES) scal->stripe[threadIdx.x].vmax_sq_bits = 0;
-}
-
-// a12: dfsph.rs:484-492
-__global__ __launch_bounds__(256) void k_predict(const float2* __restrict__ vel, const float2* __restrict__ accel, uint32_t n, float dt,
-                                                  float2* __restrict__ vstar) {
+// a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524)
+__global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float2 v = vel[i], a = accel[i];
-    vstar[i] = make_float2(v.x + a.x * dt, v.y + a.y * dt);
-}
-
-// a17: dfsph.rs:499-510
-__global__ __launch_bounds__(256) void k_advect(float2* __restrict__ pos, const float2* __restrict__ vstar, uint32_t n, float dt) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float2 p = pos[i], v = vstar[i];
-    pos[i] = make_float2(p.x + v.x * dt, p.y + v.y * dt);
+    float4 pv = PV[i];
+    const float2 a = accel[i];
+    pv.z = pv.z + a.x * dt;
+    pv.w = pv.w + a.y * dt;
+    PV[i] = pv;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// a14 / a19: compute_density_error (dfsph.rs:99-126) / compute_density_change (dfsph.rs:249-280) + block partial of Σerr
+// a14 / a19: compute_density_error (dfsph.rs:99-126) / compute_density_change (dfsph.rs:249-280), the per-particle stiffness
+// k_i = err_i * alpha_i the correction step needs (dfsph.rs:141,150 / :295,304), and the residual sum (dfsph.rs:221 / :377)
 // ------------------------------------------------------------------------------------------------------------------
 template <bool DIVERGENCE>
-__global__ __launch_bounds__(256) void k_compute_error(const float2* __restrict__ pos, const float2* __restrict__ bpos,
-                                                        const float2* __restrict__ vstar, const float* __restrict__ density, uint32_t n,
-                                                        Consts K, float dt, const uint32_t* __restrict__ list,
-                                                        const uint32_t* __restrict__ counts, float* __restrict__ err,
-                                                        float* __restrict__ warm_zero, double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
+                                                        const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
+                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
+                                                        float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
+                                                        DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float e = 0.0f;
     if (i < n) {
         const uint32_t c = counts[i];
         const uint32_t cd = c & 0xffffu, ct = c >> 16;
+        const float4 pvi = PV[i];
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
-            const float2 ri = pos[i], vi = vstar[i];
+            const float2 ri = make_float2(pvi.x, pvi.y);
             const uint32_t* lp = list + ell_index(i, 0);
             float delta = 0.0f;
-            for (uint32_t k = 0; k < cd; ++k) {
-                const uint32_t j = lp[(size_t)k * 64];
-                const float2 g = wendland_grad(K, ri, pos[j]);
-                const float2 vj = vstar[j];
-                const float dvx = vi.x - vj.x, dvy = vi.y - vj.y;
-                delta += dvx * g.x + dvy * g.y;
-            }
-            for (uint32_t k = cd; k < ct; ++k) {
-                const uint32_t j = lp[(size_t)k * 64];
-                const float2 g = wendland_grad(K, ri, bpos[j]);
-                delta += vi.x * g.x + vi.y * g.y;
+            for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
+                uint32_t j[NB_BATCH];
+                float4 r[NB_BATCH];
+#pragma unroll
+                for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
+#pragma unroll
+                for (int u = 0; u < NB_BATCH; ++u) r[u] = PV[(k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u]];
+#pragma unroll
+                for (int u = 0; u < NB_BATCH; ++u) {
+                    if (k0 + u < ct) {
+                        const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+                        // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
+                        const float dvx = pvi.z - r[u].z, dvy = pvi.w - r[u].w;
+                        delta += dvx * g.x + dvy * g.y;
+                    }
+                }
             }
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
@@ -532,32 +726,26 @@ __global__ __launch_bounds__(256) void k_compute_error(const float2* __restrict_
                 e = fmaxf(K.rho0, e) - K.rho0;         // dfsph.rs:124
             }
         }
-        err[i] = e;
+        PK[i] = make_float4(pvi.x, pvi.y, e * alpha[i], e);
         if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363, folded into the first iteration
     }
-    // fixed-shape f64 block reduction: lanes -> wave (shfl tree) -> 4 waves in order
-    double s = (double)e;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-    __shared__ double ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
-}
-
-// final residual sum (single workgroup, fixed order)
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partials, uint32_t nparts, DevScalars* __restrict__ scal) {
-    double s = 0.0;
-    for (uint32_t k = threadIdx.x; k < nparts; k += 1024) s += partials[k];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-    __shared__ double ws[16];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
+    const double bs = block_sum_f64((double)e);
+    __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += ws[k];
-        scal->err_sum = t;
+        __hip_atomic_store((unsigned long long*)&partials[blockIdx.x], (unsigned long long)__double_as_longlong(bs), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        last_s = arrive_is_last(scal) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_s) {
+        double s = 0.0;
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256)
+            s += __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s = block_sum_f64(s);
+        if (threadIdx.x == 0) {
+            mb->err_sum = s;
+            publish_common(scal, mb, seq);
+        }
     }
 }
 
@@ -565,53 +753,67 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 // a15 / a20: correct_velocity_with_{density,divergence}_error (dfsph.rs:128-161 / 282-314)
 // a16 / a21: correct_{density,divergence}_error_warmstart (dfsph.rs:163-193 / 316-344) incl. the clamp of :201-203 / :356-358
 // ------------------------------------------------------------------------------------------------------------------
-// WARM=false: k = err*alpha (own and neighbours'), warm[i] += k_i.   WARM=true: k = 0.5*max(warm, lim) (clamp applied on read).
+// WARM=false: k comes from PK (own and neighbours'), warm[i] += k_i.   WARM=true: k = 0.5*max(warm, lim) (clamp applied on read).
 template <bool WARM, bool INV_DT>
-__global__ __launch_bounds__(256) void k_correct(const float2* __restrict__ pos, const float2* __restrict__ bpos, float2* __restrict__ vstar_out,
-                                                  const float2* __restrict__ vstar_in, const float* __restrict__ err,
-                                                  const float* __restrict__ alpha, float* __restrict__ warm, uint32_t n, Consts K, float inv_dt,
-                                                  float lim, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
+                                                  uint32_t soff, Consts K, float inv_dt, float lim, const uint32_t* __restrict__ list,
+                                                  const uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = counts[i];
     const uint32_t cd = c & 0xffffu, ct = c >> 16;
-    const float2 ri = pos[i];
-    const uint32_t* lp = list + ell_index(i, 0);
+    const float4 pvi = PV[i];
     float ki;
+    float2 ri;
     if (WARM) {
         ki = 0.5f * fmaxf(warm[i], lim);
+        ri = make_float2(pvi.x, pvi.y);
     } else {
-        ki = err[i] * alpha[i];
+        const float4 pki = PK[i];
+        ki = pki.z;
+        ri = make_float2(pki.x, pki.y);
     }
+    const uint32_t* lp = list + ell_index(i, 0);
     float dx = 0.0f, dy = 0.0f;
-    for (uint32_t k = 0; k < cd; ++k) {
-        const uint32_t j = lp[(size_t)k * 64];
-        float kj;
-        if (WARM)
-            kj = 0.5f * fmaxf(warm[j], lim);
-        else
-            kj = err[j] * alpha[j];
-        const float2 g = wendland_grad(K, ri, pos[j]);
-        const float s = ki + kj;
-        dx += s * g.x;
-        dy += s * g.y;
+    for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
+        uint32_t j[NB_BATCH];
+        float4 r[NB_BATCH];
+        float wj[NB_BATCH];
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) {
+            const uint32_t idx = (k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u];
+            if (WARM) {
+                r[u] = PV[idx];
+                wj[u] = (k0 + u < cd) ? warm[j[u]] : 0.0f;
+            } else {
+                r[u] = PK[idx];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) {
+            if (k0 + u < ct) {
+                const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+                float s;
+                if (k0 + u < cd)
+                    s = ki + (WARM ? 0.5f * fmaxf(wj[u], lim) : r[u].z);  // (ki + kj), dfsph.rs:151 / :184 / :305 / :335
+                else
+                    s = ki;  // static neighbours, dfsph.rs:156 / :188 / :309 / :339
+                dx += s * g.x;
+                dy += s * g.y;
+            }
+        }
     }
-    for (uint32_t k = cd; k < ct; ++k) {
-        const uint32_t j = lp[(size_t)k * 64];
-        const float2 g = wendland_grad(K, ri, bpos[j]);
-        dx += ki * g.x;
-        dy += ki * g.y;
-    }
-    const float2 v = vstar_in[i];
     float2 o;
     if (INV_DT) {
-        o.x = v.x - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
-        o.y = v.y - (inv_dt * dy) * K.mass;
+        o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
+        o.y = pvi.w - (inv_dt * dy) * K.mass;
     } else {
-        o.x = v.x - dx * K.mass;  // dfsph.rs:312 / :342
-        o.y = v.y - dy * K.mass;
+        o.x = pvi.z - dx * K.mass;  // dfsph.rs:312 / :342
+        o.y = pvi.w - dy * K.mass;
     }
-    vstar_out[i] = o;
+    PV[i] = make_float4(pvi.x, pvi.y, o.x, o.y);
     if (!WARM) warm[i] += ki;  // dfsph.rs:142 / :296
 }
 
@@ -641,6 +843,15 @@ __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos,
     uint32_t cx, cy;
     cell_of(K, pos[i], cx, cy);
     key[i] = morton2(cx, cy);
+}
+// publish the sticky flags / neighbour-entry count outside a solver step (sphx_update_neighborhood)
+__global__ void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {
+    unsigned long long nb = 0;
+    for (uint32_t k = 0; k < STRIPES; ++k) nb += scal->stripe[k].nb_entries;
+    mb->nb_entries = nb;
+    mb->flags = scal->flags;
+    __threadfence_system();
+    __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace sphx
