@@ -16,13 +16,15 @@ namespace sphx {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_NEIGHBORS = 64;  // neighborhood_search.rs:322
-constexpr uint32_t BLOCK_CELLS = 256;   // 16x16 cells per coarse block = low 8 Morton bits
+constexpr uint32_t BLOCK_SHIFT = 6;     // directory blocks are 64x64 cells
+constexpr uint32_t BLOCK_CELLS = 4096;  // cells per block = low 12 Morton bits
 constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 threads x 16)
-constexpr uint32_t STAGE_ROWS = 32;     // neighbour rows staged in LDS per wave before the coalesced row store
+constexpr uint32_t STAGE_ROWS = 16;     // neighbour rows staged in LDS per wave before the coalesced row store
+constexpr uint32_t WIN_HALO = 512;      // neighbour build: positions of [block_first - 512, block_last + 512] are staged in LDS
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_BLOCK_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_BLOCK_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
 struct Consts {
@@ -37,13 +39,15 @@ struct Consts {
     float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
 };
 
-// Two-level Morton cell grid: coarse[] is indexed by (morton >> 8) - cbase and holds the offset of the
-// block's 256 fine entries (or EMPTY); fine[] is an exclusive prefix sum of per-cell particle counts laid out in global
-// Morton order of the occupied blocks, so fine[i+1] is always the end of cell i.
+// Two-level Morton cell grid.  dir[] is a small host-built 2D directory over the 64x64-cell blocks of the
+// covered rectangle: dir[(by-by0)*nbx + (bx-bx0)] = offset of the block's 4096 fine entries, or EMPTY.  Blocks are numbered in
+// ascending Morton order of (bx,by) and cells inside a block by the low 12 bits of their Morton code, so the fine table is in
+// GLOBAL Morton order: fine[i] = {first, one-past-last} sorted particle of cell i (exclusive prefix sum of the per-cell
+// histogram).  The table length is known on the host.
 struct GridView {
-    const uint32_t* coarse;
-    const uint32_t* fine;
-    uint32_t cbase, clen;
+    const uint32_t* dir;
+    const uint2* fine;  // {first sorted particle of the cell, one past its last}
+    uint32_t bx0, by0, nbx, nby;
 };
 
 struct alignas(128) Stripe {
@@ -53,9 +57,8 @@ struct alignas(128) Stripe {
 };
 struct DevScalars {
     uint32_t flags;        // DF_*
-    uint32_t nblk[2];      // occupied coarse blocks: [0] dynamic grid, [1] static grid
-    uint32_t fine_len[2];  // nblk*256 + 1
     uint32_t ticket;       // second-level arrival counter (one arrival per stripe); reset by the last arriver
+    uint32_t pad[30];
     Stripe stripe[STRIPES];
 };
 
@@ -70,12 +73,14 @@ struct Mailbox {
 };
 
 struct Grid {
-    uint32_t* coarse = nullptr;  // clen entries (flags during build, then offsets)
-    uint32_t* coarse_next = nullptr;  // all-zero flag buffer for the next build (cleared by this build's scan, then swapped)
-    uint32_t* fine = nullptr;    // cap_blk*256 + 1 entries
-    uint32_t cbase = 0, clen = 0, clen_cap = 0;
-    uint32_t cap_blk = 0;
-    GridView view() const { return GridView{coarse, fine, cbase, clen}; }
+    uint32_t* dir = nullptr;   // nbx*nby entries
+    uint32_t dir_cap = 0;
+    uint2* fine = nullptr;     // cell ranges of the latest build (len() entries)
+    uint32_t* hist = nullptr;  // all-zero between builds; receives the next build's per-cell histogram
+    uint32_t fine_cap = 0;     // entries allocated in fine and hist
+    uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
+    uint32_t len() const { return nblk * BLOCK_CELLS; }
+    GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
 };
 
 struct ProfTotals {
@@ -122,9 +127,10 @@ struct sphx_ctx {
     uint32_t *bid = nullptr, *bid2 = nullptr;
     // grids
     sphx::Grid gdyn, gstat;
-    uint32_t dom_x0 = 0, dom_y0 = 0, dom_x1 = 0, dom_y1 = 0;  // cell-space domain box the coarse tables cover
-    bool have_fluid_bbox = false, have_boundary_bbox = false;
-    uint32_t fb[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};  // fluid / boundary cell bboxes (x0,y0,x1,y1)
+    bool have_fluid_bbox = false;
+    uint32_t fb[4] = {0, 0, 0, 0};  // fluid cell bbox at upload (x0,y0,x1,y1)
+    bool need_expand = false;       // a particle reached the outer ring of the dynamic directory: grow it before the next build
+    std::vector<float> h_boundary;  // host copy of the boundary (caller order): the static directory is built on the host
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
     uint32_t* nb_counts = nullptr;  // (count_total << 16) | count_dynamic

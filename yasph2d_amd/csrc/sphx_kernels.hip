@@ -33,15 +33,20 @@ __device__ __forceinline__ void cell_of(const Consts& K, float2 p, uint32_t& cx,
     cy = sat_u16((p.y - K.gmin_y) * K.cell_inv);
 }
 
-__device__ __forceinline__ bool grid_range(const GridView& g, uint32_t key, uint32_t& s, uint32_t& e) {
-    const uint32_t c = (key >> 8) - g.cbase;
-    if (c >= g.clen) return false;
-    const uint32_t off = g.coarse[c];
-    if (off == EMPTY) return false;
-    const uint32_t idx = off + (key & 255u);
-    s = g.fine[idx];
-    e = g.fine[idx + 1];
-    return true;
+__device__ __forceinline__ uint32_t compact1by1(uint32_t x) {  // morton.rs:57-65
+    x &= 0x55555555u;
+    x = (x ^ (x >> 1)) & 0x33333333u;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu;
+    x = (x ^ (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+// index of cell (x,y) (Morton code `code`) in the fine table, or EMPTY if its 64x64 block is not in the directory
+__device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uint32_t y, uint32_t code) {
+    const uint32_t bx = (x >> BLOCK_SHIFT) - g.bx0, by = (y >> BLOCK_SHIFT) - g.by0;
+    if (bx >= g.nbx || by >= g.nby) return EMPTY;
+    const uint32_t off = g.dir[by * g.nbx + bx];
+    return off == EMPTY ? EMPTY : off + (code & (BLOCK_CELLS - 1u));
 }
 
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
@@ -72,6 +77,16 @@ __device__ __forceinline__ float spiky_eval(const Consts& K, float r) {
     return K.sp_norm * d * d * d;
 }
 
+// LDS reads through explicit address-space-3 pointers: hipcc otherwise merges "LDS value, or in rare cases a global value"
+// into one pointer select + flat_load, which is several times slower than a ds_read in a latency-bound loop.
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ float2 lds_read_f2(const float2* p) {
+    const unsigned long long v = *(lds_cu64*)p;
+    return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+}
+__device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
+
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -100,97 +115,6 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* to
     *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
     return base + inc - v;
-}
-
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t len, const uint32_t* __restrict__ d_len,
-                                                      uint32_t* __restrict__ partials) {
-    if (d_len) len = *d_len;
-    const uint32_t base = blockIdx.x * SCAN_TILE;
-    if (base >= len) return;
-    uint32_t s = 0;
-    const uint32_t t0 = base + threadIdx.x * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = t0 + k;
-        if (idx < len) s += in[idx];
-    }
-    uint32_t total;
-    block_excl_scan_256(s, &total);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-
-// single workgroup: exclusive scan of the tile partials; writes the grand total
-// which >= 0 (coarse pass): the total is the number of occupied blocks -> clamp to cap_blk, publish nblk and fine_len = nblk*256+1
-__global__ __launch_bounds__(1024) void k_scan_partials(uint32_t* __restrict__ partials, uint32_t len, const uint32_t* __restrict__ d_len,
-                                                         DevScalars* __restrict__ scal, int which, uint32_t cap_blk) {
-    if (d_len) len = *d_len;
-    const uint32_t ntiles = (len + SCAN_TILE - 1) / SCAN_TILE;
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t start = 0; start < ntiles; start += 1024) {
-        const uint32_t idx = start + threadIdx.x;
-        const uint32_t v = idx < ntiles ? partials[idx] : 0;
-        const uint32_t inc = wave_incl_scan(v);
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t base = carry_s;
-        for (int k = 0; k < w; ++k) base += wsum[k];
-        if (idx < ntiles) partials[idx] = base + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = base + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && which >= 0) {
-        uint32_t nb = carry_s;
-        if (nb > cap_blk) nb = cap_blk;
-        scal->nblk[which] = nb;
-        scal->fine_len[which] = nb * BLOCK_CELLS + 1;
-    }
-}
-
-// MODE 0: out[i] = exclusive prefix.  MODE 1 (coarse table): in[i] is a 0/1 flag, out[i] = flag ? prefix*256 : EMPTY,
-// blocks beyond cap_blk are dropped (EMPTY) and DF_BLOCK_CAP is raised.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t len,
-                                                     const uint32_t* __restrict__ d_len, const uint32_t* __restrict__ partials, uint32_t cap_blk,
-                                                     DevScalars* __restrict__ scal, uint32_t* __restrict__ zero_out) {
-    if (d_len) len = *d_len;
-    const uint32_t base = blockIdx.x * SCAN_TILE;
-    if (base >= len) return;
-    uint32_t v[16];
-    uint32_t s = 0;
-    const uint32_t t0 = base + threadIdx.x * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = t0 + k;
-        v[k] = idx < len ? in[idx] : 0;
-        s += v[k];
-    }
-    uint32_t total;
-    uint32_t run = block_excl_scan_256(s, &total) + partials[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = t0 + k;
-        if (idx < len) {
-            if (MODE == 0) {
-                out[idx] = run;
-            } else {
-                uint32_t o = EMPTY;
-                if (v[k]) {
-                    if (run < cap_blk)
-                        o = run * BLOCK_CELLS;
-                    else
-                        atomicOr(&scal->flags, DF_BLOCK_CAP);
-                }
-                out[idx] = o;
-                if (zero_out) zero_out[idx] = 0;  // flag buffer of the NEXT build
-            }
-        }
-        run += v[k];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -245,68 +169,148 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// device-wide exclusive scan of the per-cell histogram, 2 launches: (1) tile sums; the LAST workgroup to arrive scans the tile
+// sums in place; (2) per-tile scan + tile offset.  The histogram buffer is cleared on the way so it is all-zero again for the
+// next build.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t len, uint32_t* __restrict__ partials,
+                                                      DevScalars* __restrict__ scal) {
+    const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t s = 0;
+    const uint32_t t0 = base + threadIdx.x * 16;
+    if (t0 + 16 <= len) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(in + t0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 v = p4[k];
+            s += v.x + v.y + v.z + v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (t0 + k < len) s += in[t0 + k];
+    }
+    uint32_t total;
+    block_excl_scan_256(s, &total);
+    __shared__ uint32_t last_s, carry_s;
+    __shared__ uint32_t wsum[4];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = arrive_is_last(scal) ? 1u : 0u;
+        carry_s = 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // exclusive scan of the gridDim.x tile sums, 256 at a time
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t start = 0; start < gridDim.x; start += 256) {
+        const uint32_t idx = start + threadIdx.x;
+        const uint32_t v = idx < gridDim.x ? __hip_atomic_load(&partials[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t b = carry_s;
+        for (int k = 0; k < w; ++k) b += wsum[k];
+        if (idx < gridDim.x) partials[idx] = b + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = b + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// out[i] = {exclusive prefix of in[], + in[i]} = the cell's particle range; in[] is zeroed
+__global__ __launch_bounds__(256) void k_scan_apply(uint32_t* __restrict__ in, uint2* __restrict__ out, uint32_t len,
+                                                     const uint32_t* __restrict__ partials) {
+    const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t v[16];
+    uint32_t s = 0;
+    const uint32_t t0 = base + threadIdx.x * 16;
+    const bool full = t0 + 16 <= len;
+    if (full) {
+        uint4* p4 = reinterpret_cast<uint4*>(in + t0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 q = p4[k];
+            v[4 * k] = q.x;
+            v[4 * k + 1] = q.y;
+            v[4 * k + 2] = q.z;
+            v[4 * k + 3] = q.w;
+            p4[k] = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = (t0 + k < len) ? in[t0 + k] : 0;
+            if (t0 + k < len) in[t0 + k] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(s, &total) + partials[blockIdx.x];
+    if (full) {
+        uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 q;
+            q.x = run;
+            run += v[2 * k];
+            q.y = run;
+            q.z = run;
+            run += v[2 * k + 1];
+            q.w = run;
+            o4[k] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (t0 + k < len) out[t0 + k] = make_uint2(run, run + v[k]);
+            run += v[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // grid build: a1 (cell index), a2 (counting sort by Morton key, stable), a3 (gather), a4 (cells = fine table)
 // ------------------------------------------------------------------------------------------------------------------
-// a1: neighborhood_search.rs:111-114 — key_i = morton(cell(pos_i)); marks the particle's coarse block as occupied.
-__global__ __launch_bounds__(256) void k_cell_key(const float2* __restrict__ pos, uint32_t n, Consts K, uint32_t* __restrict__ key,
-                                                   uint32_t* __restrict__ coarse_flags, uint32_t cbase, uint32_t clen,
-                                                   DevScalars* __restrict__ scal) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t cx, cy;
-    cell_of(K, pos[i], cx, cy);
-    const uint32_t k = morton2(cx, cy);
-    key[i] = k;
-    const uint32_t c = (k >> 8) - cbase;
-    if (c < clen)
-        coarse_flags[c] = 1;
-    else
-        atomicOr(&scal->flags, DF_OUT_OF_DOMAIN);
-}
-
-// a17 + a1 fused: advect (dfsph.rs:499-510) and the cell key of the new position in one pass
-__global__ __launch_bounds__(256) void k_advect_key(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t n, float dt, Consts K,
-                                                     uint32_t* __restrict__ key, uint32_t* __restrict__ coarse_flags, uint32_t cbase,
-                                                     uint32_t clen, DevScalars* __restrict__ scal) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float4 pv = PV[i];
-    pv.x = pv.x + pv.z * dt;
-    pv.y = pv.y + pv.w * dt;
-    PV[i] = pv;
-    const float2 p = make_float2(pv.x, pv.y);
-    posA[i] = p;
-    uint32_t cx, cy;
-    cell_of(K, p, cx, cy);
-    const uint32_t k = morton2(cx, cy);
-    key[i] = k;
-    const uint32_t c = (k >> 8) - cbase;
-    if (c < clen)
-        coarse_flags[c] = 1;
-    else
-        atomicOr(&scal->flags, DF_OUT_OF_DOMAIN);
-}
-
-__global__ __launch_bounds__(256) void k_clear_fine(uint32_t* __restrict__ fine, const uint32_t* __restrict__ d_len) {
-    const uint32_t len = *d_len;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) fine[i] = 0;
-}
-
-// Per-cell histogram.  Particles arrive almost sorted (they were in cell order one step ago), so equal cells sit in adjacent
-// lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.  The value returned is an arbitrary
-// arrival slot inside the cell; k_rank_gather restores the stable order.
-__global__ __launch_bounds__(256) void k_cell_count(const uint32_t* __restrict__ key, uint32_t n, GridView g, uint32_t* __restrict__ fine,
-                                                     uint32_t* __restrict__ slot) {
+// a1 (+a17): cell of every particle (neighborhood_search.rs:111-114) and the per-cell histogram in one pass.  ADVECT fuses the
+// position update x += v* dt (dfsph.rs:499-510) in front.  Particles arrive almost sorted (they were in cell order one step
+// ago), so equal cells sit in adjacent lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.
+// The value returned by the atomic is an arbitrary arrival slot inside the cell; k_rank_gather restores the stable order.
+// cidx[i] = the particle's index into the fine table (kept for scatter/gather).
+template <bool ADVECT>
+__global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, float2* __restrict__ posA, const float2* __restrict__ pos_in,
+                                                    uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
+                                                    uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
+                                                    DevScalars* __restrict__ scal) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = EMPTY;
     if (i < n) {
-        const uint32_t k = key[i];
-        const uint32_t c = (k >> 8) - g.cbase;
-        if (c < g.clen) {
-            const uint32_t off = g.coarse[c];
-            if (off != EMPTY) idx = off + (k & 255u);
+        float2 p;
+        if (ADVECT) {
+            float4 pv = PV[i];
+            pv.x = pv.x + pv.z * dt;
+            pv.y = pv.y + pv.w * dt;
+            PV[i] = pv;
+            p = make_float2(pv.x, pv.y);
+            posA[i] = p;
+        } else {
+            p = pos_in[i];
         }
+        uint32_t cx, cy;
+        cell_of(K, p, cx, cy);
+        const uint32_t code = morton2(cx, cy);
+        idx = grid_slot(g, cx, cy, code);
+        uint32_t f = 0;
+        if (idx == EMPTY) f |= DF_OUT_OF_DOMAIN;
+        if (ring) {  // dynamic grid: warn the host long before a particle can leave the covered rectangle
+            const uint32_t bx = (cx >> BLOCK_SHIFT) - g.bx0, by = (cy >> BLOCK_SHIFT) - g.by0;
+            if (bx == 0 || by == 0 || bx + 1 >= g.nbx || by + 1 >= g.nby) f |= DF_NEAR_EDGE;
+        }
+        if (f && (__hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&scal->flags, f);
+        cidx[i] = idx;
     }
     const uint32_t prev = __shfl_up(idx, 1, 64);
     const bool head = (lane == 0) || (idx != prev);
@@ -315,21 +319,19 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t* __restrict__
     const unsigned long long rest = (lane == 63) ? 0ull : (mask >> (lane + 1));
     const uint32_t end = rest ? lane + (uint32_t)__ffsll((long long)rest) : 64u;
     uint32_t base = 0;
-    if (head && idx != EMPTY) base = atomicAdd(&fine[idx], end - lane);
+    if (head && idx != EMPTY) base = atomicAdd(&hist[idx], end - lane);
     base = __shfl(base, start, 64);
     if (i < n) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
 }
 
 // order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order)
-__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot, uint32_t n, GridView g,
-                                                  uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
+                                                  const uint2* __restrict__ fine, uint32_t* __restrict__ order) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t sl = slot[i];
     if (sl == EMPTY) return;
-    const uint32_t k = key[i];
-    const uint32_t off = g.coarse[(k >> 8) - g.cbase];
-    const uint32_t p = g.fine[off + (k & 255u)] + sl;
+    const uint32_t p = fine[cidx[i]].x + sl;
     if (p < n) order[p] = i;
 }
 
@@ -345,15 +347,17 @@ struct GatherArgs {
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
-__global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ order, const uint32_t* __restrict__ key, uint32_t n, GridView g,
-                                                      GatherArgs a) {
+__global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cidx, uint32_t n,
+                                                      const uint2* __restrict__ fine, GatherArgs a) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t i = order[p];
     if (i >= n) return;
-    const uint32_t k = key[i];
-    uint32_t s, e;
-    if (!grid_range(g, k, s, e)) return;
+    const uint32_t ci = cidx[i];
+    if (ci == EMPTY) return;
+    const uint2 se = fine[ci];
+    const uint32_t s = se.x;
+    uint32_t e = se.y;
     if (e > n) e = n;
     uint32_t rank = 0;
     for (uint32_t q = s; q < e; ++q) rank += (order[q] < i) ? 1u : 0u;
@@ -430,21 +434,22 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
     SPHX_CE(c2, c3)
 }
 
-// particle ranges of 9 (ascending) cell codes; the coarse entry is re-read only when the 16x16 block changes
+// particle ranges of 9 (ascending) cell codes; the directory entry is re-read only when the 64x64 block changes
 __device__ __forceinline__ void lookup9(const GridView& g, const uint32_t (&c)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
     uint32_t pblk = 0xFFFFFFFFu, poff = EMPTY;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const uint32_t blk = (c[t] >> 8) - g.cbase;
+        const uint32_t blk = c[t] >> (2 * BLOCK_SHIFT);
         if (blk != pblk) {
-            poff = (blk < g.clen) ? g.coarse[blk] : EMPTY;
+            const uint32_t bx = compact1by1(blk) - g.bx0, by = compact1by1(blk >> 1) - g.by0;
+            poff = (bx < g.nbx && by < g.nby) ? g.dir[by * g.nbx + bx] : EMPTY;
             pblk = blk;
         }
         uint32_t a = 0, b = 0;
         if (poff != EMPTY && c[t] != 0xFFFFFFFFu) {
-            const uint32_t idx = poff + (c[t] & 255u);
-            a = g.fine[idx];
-            b = g.fine[idx + 1];
+            const uint2 se = g.fine[poff + (c[t] & (BLOCK_CELLS - 1u))];
+            a = se.x;
+            b = se.y;
         }
         s[t] = a;
         e[t] = b;
@@ -456,58 +461,60 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
                                                          float* __restrict__ density, float* __restrict__ alpha,
                                                          DevScalars* __restrict__ scal) {
-    __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..31 of each wave, written out as whole 256-byte rows
+    __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
+    __shared__ float2 win[256 + 2 * WIN_HALO];  // positions of the sorted particles around this workgroup's 256
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
+    // hundred sorted slots, so the candidate scan below reads LDS instead of issuing ~40 scattered global loads per wave.
+    const uint32_t b0 = blockIdx.x * 256;
+    const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
+    const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
+    for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
+    __syncthreads();
     uint32_t cd = 0, ct = 0;
+    float2 pi = make_float2(0.0f, 0.0f);
     if (i < n) {
-        const float2 pi = posA[i];
+        pi = lds_read_f2(&win[i - w0]);
         uint32_t cx, cy;
         cell_of(K, pi, cx, cy);
-        // Morton codes of the 3x3 box; cells outside the u16 range get the (never occupied) code 0xFFFFFFFF.
+        // Morton codes of the 3x3 box (3 + 3 bit spreads); cells outside the u16 range get the never-occupied code 0xFFFFFFFF
+        uint32_t px[3], py[3];
+        bool vx[3], vy[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
+            vx[d] = x < 65535u;
+            vy[d] = y < 65535u;
+            px[d] = part1by1(x);
+            py[d] = part1by1(y) << 1;
+        }
         uint32_t c[9];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const uint32_t x = cx + (uint32_t)dx, y = cy + (uint32_t)dy;
-                c[(dy + 1) * 3 + (dx + 1)] = (x < 65535u && y < 65535u) ? morton2(x, y) : 0xFFFFFFFFu;
-            }
+            for (int dx = 0; dx < 3; ++dx) c[dy * 3 + dx] = (vx[dx] && vy[dy]) ? (py[dy] | px[dx]) : 0xFFFFFFFFu;
         sort9(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
         uint32_t flags = 0;
-        float rho = 0.0f, gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-        if (FUSE) rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
-
-        auto accept = [&](uint32_t j, float dx, float dy, float d2) {
-            if (ct < STAGE_ROWS)
-                tile[w][ct][lane] = j;
-            else
-                list[ell_index(i, ct)] = j;
-            ct += 1;
-            if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;
-            if (FUSE) {
-                const float r = sqrtf(d2);
-                const float q = fminf(r * K.w_hinv, 1.0f);
-                const float omq = 1.0f - q;
-                const float omq_sq = omq * omq;
-                rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
-                const float sg = K.w_ngrad * omq * omq * omq;
-                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-                gsx += gx;
-                gsy += gy;
-                gss += gx * gx + gy * gy;
-            }
-        };
-
+        uint32_t* const mytile = &tile[w][0][lane];
+        // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
         uint32_t s[9], e[9];
         lookup9(gd, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             for (uint32_t j = s[t]; j < e[t]; ++j) {
-                const float2 pj = posA[j];
+                const uint32_t wj = j - w0;
+                float2 pj = lds_read_f2(&win[min(wj, wlen - 1u)]);  // always a ds_read; the rare out-of-window candidate re-reads from global
+                if (wj >= wlen) pj = posA[j];
                 const float dx = pj.x - pi.x, dy = pj.y - pi.y;
                 const float d2 = dx * dx + dy * dy;
-                if (d2 <= K.radius_sq && d2 > 1.0e-10f && ct < MAX_NEIGHBORS) accept(j, dx, dy, d2);
+                if (d2 <= K.radius_sq && d2 > 1.0e-10f && ct < MAX_NEIGHBORS) {
+                    if (ct < STAGE_ROWS)
+                        mytile[ct * 64] = j;
+                    else
+                        list[ell_index(i, ct)] = j;
+                    ct += 1;
+                }
             }
         }
         cd = ct;
@@ -520,15 +527,18 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                 const float d2 = dx * dx + dy * dy;
                 if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
                     if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
-                    if (ct < MAX_NEIGHBORS) accept(j, dx, dy, d2);
+                    if (ct < MAX_NEIGHBORS) {
+                        if (ct < STAGE_ROWS)
+                            mytile[ct * 64] = j;
+                        else
+                            list[ell_index(i, ct)] = j;
+                        ct += 1;
+                    }
                 }
             }
         }
+        if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         counts[i] = (ct << 16) | cd;
-        if (FUSE) {
-            density[i] = fmaxf(rho, K.rho0);                                    // fluidparticleworld.rs:229
-            alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);      // dfsph.rs:94
-        }
         if (flags) atomicOr(&scal->flags, flags);
     }
     // staged rows -> global, one coalesced 256-byte row per store (lanes past their own count write don't-care values)
@@ -537,6 +547,37 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     const size_t row0 = (size_t)(i >> 6) * 64;
     for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = tile[w][k][lane];
+
+    if (FUSE && i < n) {
+        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order
+        float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
+        float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
+        for (uint32_t k = 0; k < ct; ++k) {
+            uint32_t j = lds_read_u32(&tile[w][min(k, STAGE_ROWS - 1u)][lane]);
+            if (k >= STAGE_ROWS) j = list[ell_index(i, k)];
+            float2 rj;
+            if (k < cd) {
+                const uint32_t wj = j - w0;
+                rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
+                if (wj >= wlen) rj = posA[j];
+            } else {
+                rj = posA[soff + j];
+            }
+            const float dx = rj.x - pi.x, dy = rj.y - pi.y;
+            const float r = sqrtf(dx * dx + dy * dy);
+            const float q = fminf(r * K.w_hinv, 1.0f);
+            const float omq = 1.0f - q;
+            const float omq_sq = omq * omq;
+            rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
+            const float sg = K.w_ngrad * omq * omq * omq;
+            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+            gsx += gx;
+            gsy += gy;
+            gss += gx * gx + gy * gy;
+        }
+        density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
+        alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
+    }
     // total number of list entries (stats only): block reduce, one striped atomic per workgroup
     unsigned long long tot = ct;
 #pragma unroll
