@@ -502,9 +502,12 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         lookup9(gd, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            // software pipeline: the next candidate's ds_read is in flight while the current one is tested
+            float2 pn = lds_read_f2(&win[min(s[t] - w0, wlen - 1u)]);
             for (uint32_t j = s[t]; j < e[t]; ++j) {
                 const uint32_t wj = j - w0;
-                float2 pj = lds_read_f2(&win[min(wj, wlen - 1u)]);  // always a ds_read; the rare out-of-window candidate re-reads from global
+                float2 pj = pn;  // always from LDS; the rare out-of-window candidate re-reads from global
+                pn = lds_read_f2(&win[min(wj + 1u, wlen - 1u)]);
                 if (wj >= wlen) pj = posA[j];
                 const float dx = pj.x - pi.x, dy = pj.y - pi.y;
                 const float d2 = dx * dx + dy * dy;
@@ -518,6 +521,15 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
             }
         }
         cd = ct;
+        // static neighbours: only waves that have a boundary block within one cell of some lane enter this section
+        bool near_static = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t bx = ((cx + ((q & 1) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.bx0;
+            const uint32_t by = ((cy + ((q & 2) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.by0;
+            if (bx < gs.nbx && by < gs.nby) near_static |= gs.dir[by * gs.nbx + bx] != EMPTY;
+        }
+        if (__any(near_static)) {
         lookup9(gs, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -536,6 +548,7 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                     }
                 }
             }
+        }
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         counts[i] = (ct << 16) | cd;
