@@ -1,0 +1,113 @@
+"""GPU tests at BASELINE.json's full single-GPU size (1 M particles) and of the grid-directory growth path."""
+import numpy as np
+import pytest
+from util import assert_bits_equal, assert_same_neighbors, brute_force_neighbors, dam_break
+
+import yasph2d_amd as y
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def step(ctx, timer, diam=np.float32(0.01)):
+    vmax = ctx.step_begin(timer.simulation_step())
+    dt_ns = timer.update_simulation_step(diam, vmax)
+    return ctx.step_finish(y.duration_as_secs_f32(dt_ns)), dt_ns
+
+
+def test_one_million_particles_three_steps_bit_exact():
+    """configs[1] (1 M-particle dam-break): the oracle needs ~1 s per step, so 3 steps are compared in full."""
+    pos, boundary = dam_break(float(np.sqrt(1.0e6 / 4050.0)))
+    assert 990_000 < len(pos) < 1_010_000
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    o = Oracle()
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    timer = y.TimeManager()
+    for s in range(3):
+        st, dt_ns = step(ctx, timer)
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns()
+        for k in ("density_iterations", "divergence_iterations", "neighbor_entries"):
+            assert st[k] == so[k], (s, k)
+    d = ctx.download()
+    assert_bits_equal(d["pos"], o.positions(), "positions")
+    assert_bits_equal(d["vel"], o.velocities(), "velocities")
+    assert_bits_equal(d["density"], o.densities(), "densities")
+    np.testing.assert_array_equal(d["ids"], o.ids())
+    assert_same_neighbors(ctx.download_neighbors(), o.neighbors())
+    for static in (False, True):
+        f1, c1 = ctx.download_cells(static)
+        f2, c2 = o.cells(static)
+        np.testing.assert_array_equal(c1, c2)
+        np.testing.assert_array_equal(f1, f2)
+
+
+def test_one_million_particles_properties_after_60_steps():
+    """Size-independent properties at full size: sortedness, permutation, list symmetry, brute force on a sample."""
+    pos, boundary = dam_break(float(np.sqrt(1.0e6 / 4050.0)))
+    n = len(pos)
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    entries = 0
+    for _ in range(60):
+        st, _ = step(ctx, timer)
+        entries = st["neighbor_entries"]
+    d = ctx.download()
+    p, ids = d["pos"], d["ids"]
+    assert np.isfinite(p).all() and np.isfinite(d["vel"]).all()
+    assert (d["density"] >= np.float32(100.0)).all()  # clamp of fluidparticleworld.rs:229
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))  # a permutation of the uploaded particles
+    first, cidx = ctx.download_cells()
+    assert first[-1] == n and cidx[-1] == 0xFFFFFFFF
+    assert (np.diff(cidx[:-1].astype(np.int64)) > 0).all()  # Morton-sorted, one entry per non-empty cell
+    counts, start, lists = ctx.download_neighbors()
+    assert int(counts[:, 1].astype(np.int64).sum()) == entries == len(lists)
+    assert counts[:, 1].max() <= 64
+    # dynamic lists are symmetric: j in N(i) <=> i in N(j)
+    cd = counts[:, 0].astype(np.int64)
+    owner = np.repeat(np.arange(n, dtype=np.int64), counts[:, 1].astype(np.int64))
+    k_in_list = np.arange(len(lists), dtype=np.int64) - np.repeat(start[:-1].astype(np.int64), counts[:, 1].astype(np.int64))
+    dyn = k_in_list < cd[owner]
+    a, b = owner[dyn], lists[dyn].astype(np.int64)
+    fwd = np.sort(a * n + b)
+    rev = np.sort(b * n + a)
+    assert np.array_equal(fwd, rev)
+    # ascending order inside each dynamic list and exact membership on a random sample
+    rng = np.random.default_rng(5)
+    h = np.float32(0.02)
+    for i in rng.integers(0, n, 200):
+        got = lists[int(start[i]):int(start[i]) + int(cd[i])]
+        assert (np.diff(got.astype(np.int64)) > 0).all()
+        lo, hi = max(0, int(got.min()) - 2000 if len(got) else 0), n
+        np.testing.assert_array_equal(got, brute_force_neighbors(p, h, i))
+
+
+def test_directory_grows_with_the_fluid():
+    """A blob in free fall without any boundary leaves the initially covered 64x64-cell blocks: the host must grow the block
+    directory in time (DF_NEAR_EDGE path) and the results must stay bit-identical to the oracle, which has no such table."""
+    rng = np.random.default_rng(2)
+    side = 24
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(np.float32)
+    pos = (np.float32(1.0) + g * np.float32(0.0111) + rng.random((side * side, 2), dtype=np.float32) * np.float32(0.0005)).astype(np.float32)
+    vel = np.tile(np.array([[6.0, 0.0]], np.float32), (len(pos), 1))
+    ctx = y.SphxContext()
+    ctx.upload(pos, vel)
+    o = Oracle()
+    o.set_particles(pos, vel)
+    timer = y.TimeManager()
+    x0 = pos[:, 0].mean()
+    for s in range(1500):
+        st, dt_ns = step(ctx, timer)
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns(), s
+        assert st["density_iterations"] == so["density_iterations"] and st["divergence_iterations"] == so["divergence_iterations"], s
+    d = ctx.download()
+    assert d["pos"][:, 0].mean() - x0 > 3 * 64 * 0.02  # travelled across more than three 64-cell blocks
+    assert_bits_equal(d["pos"], o.positions(), "positions")
+    assert_bits_equal(d["vel"], o.velocities(), "velocities")
+    assert_same_neighbors(ctx.download_neighbors(), o.neighbors())
