@@ -143,6 +143,29 @@ int sphx_download_cells(sphx_ctx* ctx, int which, uint32_t* first_particle, uint
  * out[3..5] = Poly6 {hsq, normalizer, normalizer_grad} (poly6.rs:16-23) */
 int sphx_get_constants(const sphx_ctx* ctx, float* out6);
 
+
+/* ---- spatial tiles (multi-GPU) ------------------------------------------------------------------------------
+ * The reference has no distributed path; these entry points are the device half of the build's own domain decomposition.
+ * One context = one tile: the cells with cell_lo <= c < cell_hi along `axis` (0 = x, 1 = y) are OWNED, a halo of `halo_cells`
+ * cells on each side holds copies (ghosts) of the neighbours' particles.  The host driver (yasph2d_amd/tiles.py; in a Rust host
+ * this would sit inside the Solver impl) runs the sub-steps below in the order of dfsph.rs:414-525, all-reduces the three
+ * per-step scalars, and once per step — between advect and re-grid — exchanges 32-byte halo records with the two spatial
+ * neighbours (RCCL send/recv on the device buffers).  With a halo wider than the number of neighbour traversals between two
+ * exchanges, ghost values are recomputed locally instead of being exchanged per sub-step.
+ * In tile mode the warm-start arrays travel with their particle (a slot-bound array has no meaning across tiles). */
+int sphx_reserve(sphx_ctx* ctx, uint32_t capacity); /* device capacity in particles (owned + ghosts + 2 halo buffers); before upload */
+int sphx_tile_configure(sphx_ctx* ctx, int axis, uint32_t cell_lo, uint32_t cell_hi, uint32_t halo_cells, int has_left, int has_right);
+int sphx_tile_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, const uint32_t* ids, uint32_t n); /* owned particles, global ids < 2^31 */
+#define SPHX_HALO_RECORD_BYTES 32 /* {float4 pos+vel, u32 id, f32 kappa, f32 stiffness, u32 pad}; record 0 = header (count in .id) */
+int sphx_tile_pack(sphx_ctx* ctx, void* d_send_left, void* d_send_right, uint32_t cap_records);              /* DEVICE buffers, (1+cap)*32 B */
+int sphx_tile_apply(sphx_ctx* ctx, const void* d_from_left, const void* d_from_right, uint32_t cap_records); /* DEVICE buffers or NULL */
+int sphx_sub_regrid(sphx_ctx* ctx, uint32_t* out_n_local);                 /* dfsph.rs:512-518 on owned + ghosts */
+int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
+int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
+int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */
+int sphx_sub_iteration(sphx_ctx* ctx, int divergence, float dt, int first, double* out_err_sum, uint64_t* out_n_owned); /* :217-221 / :372-377 */
+int sphx_sub_advect(sphx_ctx* ctx, float dt);                              /* dfsph.rs:499-510 */
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 int sphx_synchronize(sphx_ctx* ctx);
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream; totals are kept per kernel name. */

@@ -113,6 +113,14 @@ def lib(omp=False):
         "orc_get_neighbor_counts": (u64, [vp, vp]),
         "orc_get_neighbor_lists": (None, [vp, vp]),
         "orc_get_neighbor_flags": (u32, [vp]),
+        "orc_tile_configure": (None, [vp, i32, u32, u32]),
+        "orc_tile_set_state": (None, [vp, vp, vp, vp, vp, vp, u32]),
+        "orc_sub_regrid": (None, [vp]),
+        "orc_sub_nonpressure": (f32, [vp, f32]),
+        "orc_sub_predict": (None, [vp, f32]),
+        "orc_sub_warmstart": (None, [vp, i32, f32]),
+        "orc_sub_iteration": (C.c_double, [vp, i32, f32, i32]),
+        "orc_sub_advect": (None, [vp, f32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

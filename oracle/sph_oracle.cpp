@@ -1057,7 +1057,13 @@ struct WCSPHSolver {  // wscsph.rs:14-23
 // =====================================================================================
 // C API (ctypes)
 // =====================================================================================
+struct OrcTile {  // spatial-tile test support (see the sub-step API at the end of this file)
+    int axis = 0;
+    uint32_t lo = 0, hi = 65536;
+    std::vector<V2> accel;
+};
 struct OrcSim {
+    OrcTile tile;
     World world;
     DFSPHSolver dfsph;
     WCSPHSolver wcsph;
@@ -1296,5 +1302,105 @@ void orc_get_neighbor_lists(OrcSim* s, uint32_t* out) {
     }
 }
 uint32_t orc_get_neighbor_flags(OrcSim* s) { return s->world.neighborhood.neighbor_lists.overflow_flags; }
+
+
+// ---- sub-step API for the spatial-tile tests (tests/tile_oracle_backend.py) -------------------------------------------------
+// The product's multi-GPU driver (yasph2d_amd/tiles.py) is backend-agnostic; the CPU tests run it over this oracle with gloo.
+// A tile holds owned + ghost particles in ONE local array; reductions only count particles whose cell coordinate along
+// `axis` lies in [lo, hi).  In tile mode the warm-start arrays travel with their particle (they cannot stay slot-bound
+// across tiles), everything else is the reference's per-particle arithmetic, unchanged.
+static inline bool tile_owns(OrcSim* s, const OrcTile& t, V2 p) {  // C linkage is fine for a static helper
+    uint16_t cx, cy;
+    s->world.neighborhood.grid.position_to_cell(p, cx, cy);
+    const uint32_t c = t.axis ? cy : cx;
+    return c >= t.lo && c < t.hi;
+}
+void orc_tile_configure(OrcSim* s, int axis, uint32_t lo, uint32_t hi) {
+    OrcTile& t = s->tile;
+    t.axis = axis;
+    t.lo = lo;
+    t.hi = hi;
+}
+void orc_tile_set_state(OrcSim* s, const float* pos, const float* vel, const uint32_t* ids, const float* kappa, const float* stiff, uint32_t n) {
+    World& w = s->world;
+    w.positions.resize(n);
+    w.velocities.resize(n);
+    w.densities.assign(n, 0.0f);
+    w.ids.resize(n);
+    s->dfsph.warmstart_kappa.resize(n);
+    s->dfsph.warmstart_stiffness.resize(n);
+    s->dfsph.alpha_values.assign(n, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        w.positions[i] = v2(pos[2 * i], pos[2 * i + 1]);
+        w.velocities[i] = v2(vel[2 * i], vel[2 * i + 1]);
+        w.ids[i] = ids[i];
+        s->dfsph.warmstart_kappa[i] = kappa ? kappa[i] : 0.0f;
+        s->dfsph.warmstart_stiffness[i] = stiff ? stiff[i] : 0.0f;
+    }
+}
+void orc_sub_regrid(OrcSim* s) {  // dfsph.rs:512-518 on the local set
+    World& w = s->world;
+    s->dfsph.alpha_values.resize(w.positions.size(), 0.0f);
+    w.update_neighborhood_datastructure({}, {&s->dfsph.warmstart_kappa, &s->dfsph.warmstart_stiffness});
+    w.update_densities(s->dfsph.kernel);
+    s->dfsph.compute_alpha_factors(w);
+}
+float orc_sub_nonpressure(OrcSim* s, float dt) {  // dfsph.rs:436-477; returns max |v + a dt|^2 over owned particles
+    World& w = s->world;
+    OrcTile& t = s->tile;
+    const size_t n = w.positions.size();
+    t.accel.resize(n);
+    const Real particle_mass = w.particle_mass();
+    const V2 non_pressure_accelleration = (w.gravity * particle_mass) / particle_mass;
+    const NeighborLists& nl = w.neighborhood.neighbor_lists;
+    Real max_velocity_sq = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const V2 ri = w.positions[i], vi = w.velocities[i];
+        V2 a = non_pressure_accelleration;
+        uint32_t cnt;
+        const uint32_t* nb = nl.neighbors_dynamic((uint32_t)i, cnt);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t j = nb[k];
+            const Real r_sq = magnitude2(w.positions[j] - ri);
+            a = a + s->dfsph.viscosity_model.compute_viscous_accelleration(dt, r_sq, std::sqrt(r_sq), particle_mass, w.densities[j], w.velocities[j] - vi);
+        }
+        t.accel[i] = a;
+        if (tile_owns(s, t, ri)) max_velocity_sq = rs_max(max_velocity_sq, magnitude2(vi + a * dt));
+    }
+    return max_velocity_sq;
+}
+void orc_sub_predict(OrcSim* s, float dt) {  // dfsph.rs:484-492, in place (the old velocity is dead afterwards, dfsph.rs:524)
+    World& w = s->world;
+    OrcTile& t = s->tile;
+    for (size_t i = 0; i < w.positions.size(); ++i) w.velocities[i] = w.velocities[i] + t.accel[i] * dt;
+}
+void orc_sub_warmstart(OrcSim* s, int divergence, float dt) {  // dfsph.rs:199-205 / :354-360
+    World& w = s->world;
+    std::vector<Real>& warm = divergence ? s->dfsph.warmstart_stiffness : s->dfsph.warmstart_kappa;
+    const Real lim = -0.5f * w.fluid_density * w.fluid_density;
+    for (auto& k : warm) k = 0.5f * rs_max(k, lim);
+    s->dfsph.correct_warmstart(!divergence, dt, w, w.velocities, warm);
+}
+double orc_sub_iteration(OrcSim* s, int divergence, float dt, int first) {  // dfsph.rs:217-221 / :372-377; f64 sum over owned
+    World& w = s->world;
+    OrcTile& t = s->tile;
+    std::vector<Real>& warm = divergence ? s->dfsph.warmstart_stiffness : s->dfsph.warmstart_kappa;
+    if (first)
+        for (auto& k : warm) k = 0.0f;
+    std::vector<Real> err(w.positions.size());
+    if (divergence)
+        s->dfsph.compute_density_change(w, w.velocities, err);
+    else
+        s->dfsph.compute_density_error(dt, w, w.velocities, err);
+    s->dfsph.correct_velocity(!divergence, dt, w, w.velocities, err, warm);
+    double sum = 0.0;
+    for (size_t i = 0; i < err.size(); ++i)
+        if (tile_owns(s, t, w.positions[i])) sum += (double)err[i];
+    return sum;
+}
+void orc_sub_advect(OrcSim* s, float dt) {  // dfsph.rs:499-510
+    World& w = s->world;
+    for (size_t i = 0; i < w.positions.size(); ++i) w.positions[i] = w.positions[i] + w.velocities[i] * dt;
+}
 
 }  // extern "C"

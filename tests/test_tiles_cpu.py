@@ -1,0 +1,149 @@
+"""Multi-GPU path on CPU: the tile driver (yasph2d_amd/tiles.py — partitioning, halo records, migration, ring budget,
+collectives) runs over the oracle backend with world_size-2 gloo processes and with in-process thread ranks, and must
+reproduce the single-domain oracle run particle by particle (by id)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+from util import dam_break
+
+import yasph2d_amd as y
+from oracle.oracle import Oracle
+from yasph2d_amd.tiles import ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def single_domain(pos, boundary, steps, fixed=(0, 0)):
+    o = Oracle()
+    o.set_fixed_iterations(*fixed)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    stats = [o.dfsph_step() for _ in range(steps)]
+    ids = o.ids()
+    inv = np.argsort(ids)
+    return dict(pos=o.positions()[inv], vel=o.velocities()[inv], density=o.densities()[inv]), stats, o.timer_step_ns()
+
+
+def run_tiles_threaded(make_backend, pos, boundary, world, axis, steps, halo=16, fixed=(0, 0)):
+    cuts = quantile_cuts(cell_coord(pos, axis), world)
+    shared = ThreadComm.Shared(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            t = TiledDFSPH(make_backend(r), ThreadComm(shared, r), axis, cuts, halo=halo, fixed_iterations=fixed)
+            t.setup(pos, None, None, boundary)
+            timer = y.TimeManager()
+            stats = [t.step(timer) for _ in range(steps)]
+            out[r] = (t.download_owned(), stats, t.exchanges)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return out, cuts
+
+
+def merge_owned(outs, n):
+    pos, vel, den = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+    seen = np.zeros(n, np.int32)
+    for d, _, _ in outs:
+        pos[d["ids"]], vel[d["ids"]], den[d["ids"]] = d["pos"], d["vel"], d["density"]
+        seen[d["ids"]] += 1
+    assert (seen == 1).all(), "every particle must be owned by exactly one tile"
+    return pos, vel, den
+
+
+@pytest.mark.parametrize("world,axis,halo", [(2, 1, 16), (3, 1, 8), (2, 0, 6)])
+def test_tiles_match_single_domain(world, axis, halo):
+    """Adaptive timer, 60 steps (free fall, before any warm start — the slot-bound warm-start arrays of the reference
+    cannot be reproduced across tiles): dt, iteration counts identical; positions/velocities to 1e-5 relative."""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(1.0)
+    steps = 60
+    ref, rstats, _ = single_domain(pos, boundary, steps)
+    outs, cuts = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, world, axis, steps, halo=halo)
+    for s in range(steps):
+        for r in range(world):
+            st = outs[r][1][s]
+            assert st["density_iterations"] == rstats[s]["density_iterations"] and st["divergence_iterations"] == rstats[s]["divergence_iterations"]
+            assert np.float32(st["dt"]) == np.float32(rstats[s]["dt"]) and np.float32(st["vmax"]) == np.float32(rstats[s]["vmax"])
+    p, v, d = merge_owned(outs, len(pos))
+    np.testing.assert_allclose(p, ref["pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v, ref["vel"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d, ref["density"], rtol=1e-5)
+
+
+def test_tiles_with_impact_migration_and_long_loops():
+    """Fixed 3+2 iterations per step exercise the warm-start sub-steps and the ring budget (extra exchanges), and 200 steps
+    run through the impact so particles migrate across the cut.  Warm-start values travel with the particle here, so the
+    comparison is against a threaded run with ONE tile (same sub-step code path), not the slot-bound single-domain run."""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(1.0)
+    steps = 120
+    one, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 1, 1, steps, fixed=(3, 2))
+    two, cuts = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 1, steps, fixed=(3, 2), halo=10)
+    assert two[0][2] > steps + 1, "a 10-cell halo cannot cover 5 iterations + 2 warm starts per step: extra exchanges expected"
+    p1, v1, _ = merge_owned(one, len(pos))
+    p2, v2, _ = merge_owned(two, len(pos))
+    np.testing.assert_allclose(p2, p1, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(v2, v1, rtol=2e-2, atol=2e-2)  # summation order inside cells differs between tilings; the impact amplifies it
+    # particles changed owner
+    c0 = cell_coord(pos, 1)
+    c1 = cell_coord(p2, 1)
+    assert ((c0 < cuts[1]) != (c1 < cuts[1])).sum() > 0
+
+
+GLOO_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+import torch, torch.distributed as dist
+import yasph2d_amd as y
+from yasph2d_amd.tiles import TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+from tile_oracle_backend import OracleTileBackend
+from util import dam_break
+dist.init_process_group("gloo")
+pos, boundary = dam_break(1.0)
+cuts = quantile_cuts(cell_coord(pos, 1), dist.get_world_size())
+t = TiledDFSPH(OracleTileBackend(), TorchComm(dist, torch.device("cpu")), 1, cuts, halo=16)
+t.setup(pos, None, None, boundary)
+timer = y.TimeManager()
+stats = [t.step(timer) for _ in range(int(os.environ["STEPS"]))]
+d = t.download_owned()
+np.savez(os.path.join(os.environ["OUT_DIR"], f"rank{dist.get_rank()}.npz"), pos=d["pos"], vel=d["vel"], ids=d["ids"], density=d["density"],
+         dt_ns=np.array([s["dt_ns"] for s in stats]), Id=np.array([s["density_iterations"] for s in stats]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_tiles_gloo_world_size_2(tmp_path):
+    """The N > 1 launch path of bench.py: one process per rank, torch.distributed (gloo here, RCCL on the GPUs)."""
+    import subprocess
+
+    steps = 40
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, REPO_ROOT=os.path.dirname(HERE), OUT_DIR=str(tmp_path), STEPS=str(steps), OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29531", str(script)], env=env, timeout=600)
+    pos, boundary = dam_break(1.0)
+    ref, rstats, timer_ns = single_domain(pos, boundary, steps)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    ids = np.concatenate([p["ids"] for p in parts])
+    assert sorted(ids.tolist()) == list(range(len(pos)))
+    got = np.zeros_like(ref["pos"])
+    got[ids] = np.concatenate([p["pos"] for p in parts])
+    np.testing.assert_allclose(got, ref["pos"], rtol=1e-5, atol=1e-6)
+    for p in parts:
+        assert int(p["dt_ns"][-1]) == timer_ns
+        np.testing.assert_array_equal(p["Id"], [s["density_iterations"] for s in rstats])

@@ -1,0 +1,118 @@
+"""CPU backend of yasph2d_amd.tiles.TiledDFSPH for the tests: the sub-steps are executed by the oracle, the halo
+pack/apply logic is restated in numpy (same selection rules and the same record order as the HIP kernels k_tile_*)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle.oracle import Oracle
+from yasph2d_amd.tiles import HALO_DTYPE, HALO_RECORD_BYTES, cell_coord
+
+OWNED = np.uint32(0x80000000)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleTileBackend:
+    def __init__(self):
+        self.o = Oracle()
+        self.L = self.o.L
+
+    def make_buffers(self, cap):
+        return [torch.zeros((1 + cap) * HALO_RECORD_BYTES, dtype=torch.uint8) for _ in range(4)]
+
+    def set_boundary(self, xy):
+        self.o.set_boundary(xy)
+
+    def configure(self, axis, lo, hi, halo, has_left, has_right):
+        self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right = axis, lo, hi, halo, has_left, has_right
+        self.L.orc_tile_configure(self.o.h, axis, lo, hi)
+
+    def reserve(self, capacity):
+        pass
+
+    def _set(self, pos, vel, ids, kappa, stiff):
+        pos, vel = np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(vel, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        kappa, stiff = np.ascontiguousarray(kappa, np.float32), np.ascontiguousarray(stiff, np.float32)
+        self.L.orc_tile_set_state(self.o.h, _p(pos), _p(vel), _p(ids), _p(kappa), _p(stiff), len(pos))
+
+    def _state(self):
+        n = self.o.n
+        return self.o.positions(), self.o.velocities(), self.o.ids(), (self.o.kappa() if n else np.zeros(0, np.float32)), (
+            self.o.stiffness() if n else np.zeros(0, np.float32))
+
+    def upload(self, pos, vel, ids):
+        n = len(pos)
+        self._set(pos, vel, np.asarray(ids, np.uint32) | OWNED, np.zeros(n, np.float32), np.zeros(n, np.float32))
+
+    def pack(self, send_left, send_right, cap):
+        pos, vel, ids, kappa, stiff = self._state()
+        owned = (ids >> np.uint32(31)) != 0
+        c = cell_coord(pos, self.axis)
+        for buf, has, sel in ((send_left, self.has_left, owned & (c < self.lo + self.halo)), (send_right, self.has_right, owned & (c + self.halo >= self.hi))):
+            rec = buf.numpy().view(HALO_DTYPE)
+            rec[:] = 0
+            if not has:
+                continue
+            idx = np.nonzero(sel)[0]
+            assert len(idx) <= cap, "halo buffer too small"
+            rec["id"][0] = len(idx)
+            r = rec[1:1 + len(idx)]
+            r["pv"][:, :2] = pos[idx]
+            r["pv"][:, 2:] = vel[idx]
+            r["id"] = ids[idx] & np.uint32(0x7FFFFFFF)
+            r["kappa"] = kappa[idx]
+            r["stiff"] = stiff[idx]
+
+    def apply(self, recv_left, recv_right, cap):
+        pos, vel, ids, kappa, stiff = self._state()
+        owned = (ids >> np.uint32(31)) != 0
+        c = cell_coord(pos, self.axis)
+        keep = owned & (c >= self.lo) & (c < self.hi)
+        parts = [(pos[keep], vel[keep], ids[keep], kappa[keep], stiff[keep])]
+        for buf in (recv_left, recv_right):
+            if buf is None:
+                continue
+            rec = buf.numpy().view(HALO_DTYPE)
+            cnt = int(rec["id"][0])
+            r = rec[1:1 + cnt]
+            p, v = r["pv"][:, :2].copy(), r["pv"][:, 2:].copy()
+            cc = cell_coord(p, self.axis)
+            own = (cc >= self.lo) & (cc < self.hi)
+            ghost = (cc + self.halo >= self.lo) & (cc < self.hi + self.halo)
+            m = own | ghost
+            parts.append((p[m], v[m], (r["id"] | np.where(own, OWNED, np.uint32(0)).astype(np.uint32))[m], r["kappa"][m], r["stiff"][m]))
+        self._set(*[np.concatenate([q[k] for q in parts]) for k in range(5)])
+
+    def regrid(self):
+        self.L.orc_sub_regrid(self.o.h)
+        return self.o.n
+
+    def nonpressure(self, dt_prev):
+        return float(self.L.orc_sub_nonpressure(self.o.h, dt_prev))
+
+    def predict(self, dt):
+        self.L.orc_sub_predict(self.o.h, dt)
+
+    def warmstart(self, divergence, dt):
+        self.L.orc_sub_warmstart(self.o.h, int(divergence), dt)
+
+    def iteration(self, divergence, dt, first):
+        s = float(self.L.orc_sub_iteration(self.o.h, int(divergence), dt, int(first)))
+        pos, _, ids, _, _ = self._state()
+        owned = ((ids >> np.uint32(31)) != 0)
+        return s, int(owned.sum())
+
+    def advect(self, dt):
+        self.L.orc_sub_advect(self.o.h, dt)
+
+    def synchronize(self):
+        pass
+
+    def download(self):
+        pos, vel, ids, kappa, stiff = self._state()
+        return dict(pos=pos, vel=vel, density=self.o.densities(), ids=ids & np.uint32(0x7FFFFFFF), owned=(ids >> np.uint32(31)) != 0, kappa=kappa,
+                    stiffness=stiff, alpha=self.o.alpha())

@@ -90,6 +90,17 @@ SIGNATURES = {
     "sphx_download_neighbors": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
     "sphx_download_cells": (_i, [_vp, _i, _vp, _vp, C.POINTER(_u32)]),
     "sphx_get_constants": (_i, [_vp, _vp]),
+    "sphx_reserve": (_i, [_vp, _u32]),
+    "sphx_tile_configure": (_i, [_vp, _i, _u32, _u32, _u32, _i, _i]),
+    "sphx_tile_upload": (_i, [_vp, _vp, _vp, _vp, _u32]),
+    "sphx_tile_pack": (_i, [_vp, _vp, _vp, _u32]),
+    "sphx_tile_apply": (_i, [_vp, _vp, _vp, _u32]),
+    "sphx_sub_regrid": (_i, [_vp, C.POINTER(_u32)]),
+    "sphx_sub_nonpressure": (_i, [_vp, _f, C.POINTER(_f)]),
+    "sphx_sub_predict": (_i, [_vp, _f]),
+    "sphx_sub_warmstart": (_i, [_vp, _i, _f]),
+    "sphx_sub_iteration": (_i, [_vp, _i, _f, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "sphx_sub_advect": (_i, [_vp, _f]),
     "sphx_synchronize": (_i, [_vp]),
     "sphx_profile_enable": (_i, [_vp, _i]),
     "sphx_profile_reset": (_i, [_vp]),
@@ -144,6 +155,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950).  yasph2d_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If libsphx pulled in /opt/rocm's copy first, torch.cuda would later
+    # find "No HIP GPUs" in the same process (two runtimes fighting over the device).  Loading torch first makes both share one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -37,6 +37,9 @@ struct Consts {
     float sp_h, sp_norm, sp_ngrad;   // Spiky::new (spiky.rs:16-23)
     float mass, rho0, xsph_eps;
     float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
+    // spatial tile owned by this context (multi-GPU): cells with tile_lo <= c < tile_hi along tile_axis; reductions only count
+    // owned particles.  Single-GPU default: [0, 65536).
+    uint32_t tile_axis, tile_lo, tile_hi;
 };
 
 // Two-level Morton cell grid.  dir[] is a small host-built 2D directory over the 64x64-cell blocks of the
@@ -52,13 +55,15 @@ struct GridView {
 
 struct alignas(128) Stripe {
     unsigned long long nb_entries;  // partial sum of count_total over ALL builds so far (stats only; the host takes differences)
+    unsigned long long owned;       // partial count of owned particles over ALL tile re-grids so far (host takes differences)
     uint32_t ticket;                // first-level arrival counter of the last-block reductions
-    uint32_t pad[29];
+    uint32_t pad[27];
 };
 struct DevScalars {
     uint32_t flags;        // DF_*
     uint32_t ticket;       // second-level arrival counter (one arrival per stripe); reset by the last arriver
-    uint32_t pad[30];
+    uint32_t sort_total;   // number of particles that received a cell in the latest histogram scan (tile mode: new local count)
+    uint32_t pad[29];
     Stripe stripe[STRIPES];
 };
 
@@ -70,6 +75,9 @@ struct Mailbox {
     uint32_t pad;
     double err_sum;         // residual sum of the last compute_error launch
     unsigned long long nb_entries;
+    unsigned long long owned_cum;
+    uint32_t sort_total;
+    uint32_t pad2;
 };
 
 struct Grid {
@@ -118,6 +126,7 @@ struct sphx_ctx {
     float4* PK = nullptr;                      // [N|B] {pos.x, pos.y, k = err*alpha, err}: written by compute_error, gathered by correct
     float2* accel = nullptr;                   // [N]
     float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr;  // [N]
+    float *kappa2 = nullptr, *stiff2 = nullptr;  // gather targets (tile mode only)
     uint32_t *pid = nullptr, *pid2 = nullptr;
     uint32_t *key = nullptr, *slot = nullptr, *order = nullptr;  // grid-build scratch, sized for max(N, B)
     uint32_t idx_cap = 0;
@@ -144,6 +153,13 @@ struct sphx_ctx {
     sphx::Mailbox* mbox_dev = nullptr;  // its device address
     uint32_t seq = 0;
     unsigned long long nb_cum = 0, nb_last = 0;  // cumulative neighbour-entry counter seen so far / entries of the last build
+    unsigned long long owned_cum = 0, owned_last = 0;
+    // tile mode (multi-GPU spatial decomposition)
+    bool tile_mode = false;
+    uint32_t tile_halo = 0;
+    int tile_has_left = 0, tile_has_right = 0;
+    uint32_t n_owned = 0;
+    uint2 *tile_scan_l = nullptr, *tile_scan_r = nullptr;  // [capN] send-set compaction scratch
 
     // profiling
     bool profiling = false;

@@ -33,6 +33,15 @@ __device__ __forceinline__ void cell_of(const Consts& K, float2 p, uint32_t& cx,
     cy = sat_u16((p.y - K.gmin_y) * K.cell_inv);
 }
 
+// multi-GPU tiles: a particle is OWNED by this context iff its cell coordinate along the tile axis is in [tile_lo, tile_hi)
+__device__ __forceinline__ uint32_t tile_coord(const Consts& K, float px, float py) {
+    return K.tile_axis ? sat_u16((py - K.gmin_y) * K.cell_inv) : sat_u16((px - K.gmin_x) * K.cell_inv);
+}
+__device__ __forceinline__ bool tile_owns(const Consts& K, float px, float py) {
+    const uint32_t c = tile_coord(K, px, py);
+    return c >= K.tile_lo && c < K.tile_hi;
+}
+
 __device__ __forceinline__ uint32_t compact1by1(uint32_t x) {  // morton.rs:57-65
     x &= 0x55555555u;
     x = (x ^ (x >> 1)) & 0x33333333u;
@@ -139,6 +148,10 @@ __device__ __forceinline__ bool arrive_is_last(DevScalars* scal) {  // call from
 __device__ __forceinline__ void publish_common(DevScalars* scal, Mailbox* mb, uint32_t seq) {  // one thread of the last block
     unsigned long long nb = 0;
     for (uint32_t k = 0; k < STRIPES; ++k) nb += __hip_atomic_load(&scal->stripe[k].nb_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long ow = 0;
+    for (uint32_t k = 0; k < STRIPES; ++k) ow += __hip_atomic_load(&scal->stripe[k].owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mb->owned_cum = ow;
+    mb->sort_total = __hip_atomic_load(&scal->sort_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     mb->nb_entries = nb;
     mb->flags = __hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -174,7 +187,7 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t b) {
 // next build.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t len, uint32_t* __restrict__ partials,
-                                                      DevScalars* __restrict__ scal) {
+                                                      DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total) {
     const uint32_t base = blockIdx.x * SCAN_TILE;
     uint32_t s = 0;
     const uint32_t t0 = base + threadIdx.x * 16;
@@ -216,7 +229,10 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
         if (threadIdx.x == 255) carry_s = b + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (d_total) *d_total = carry_s;  // grand total (e.g. the number of particles that got a cell)
+        __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // out[i] = {exclusive prefix of in[], + in[i]} = the cell's particle range; in[] is zeroed
@@ -302,12 +318,13 @@ __global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, floa
         uint32_t cx, cy;
         cell_of(K, p, cx, cy);
         const uint32_t code = morton2(cx, cy);
-        idx = grid_slot(g, cx, cy, code);
+        const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
+        idx = dropped ? EMPTY : grid_slot(g, cx, cy, code);
         uint32_t f = 0;
-        if (idx == EMPTY) f |= DF_OUT_OF_DOMAIN;
+        if (idx == EMPTY && !dropped) f |= DF_OUT_OF_DOMAIN;
         if (ring) {  // dynamic grid: warn the host long before a particle can leave the covered rectangle
             const uint32_t bx = (cx >> BLOCK_SHIFT) - g.bx0, by = (cy >> BLOCK_SHIFT) - g.by0;
-            if (bx == 0 || by == 0 || bx + 1 >= g.nbx || by + 1 >= g.nby) f |= DF_NEAR_EDGE;
+            if (!dropped && (bx == 0 || by == 0 || bx + 1 >= g.nbx || by + 1 >= g.nby)) f |= DF_NEAR_EDGE;
         }
         if (f && (__hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&scal->flags, f);
         cidx[i] = idx;
@@ -342,17 +359,23 @@ struct GatherArgs {
     float4* pv_out;
     const float* r_in;
     float* r_out;
-    const uint32_t* u_in;
+    const float* r2_in;  // tile mode: warm-start arrays travel with the particle (they cannot stay slot-bound across tiles)
+    float* r2_out;
+    const float* r3_in;
+    float* r3_out;
+    const uint32_t* u_in;  // particle id; bit 31 = owned by this tile
     uint32_t* u_out;
+    DevScalars* count_owned;  // tile mode: counts ids with bit 31 set
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
+// n = number of sorted slots; n_in = size of the unsorted input (larger than n when the tile path dropped particles).
 __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cidx, uint32_t n,
-                                                      const uint2* __restrict__ fine, GatherArgs a) {
+                                                      uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t i = order[p];
-    if (i >= n) return;
+    if (i >= n_in) return;
     const uint32_t ci = cidx[i];
     if (ci == EMPTY) return;
     const uint2 se = fine[ci];
@@ -371,7 +394,17 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         a.pos_out[dst] = a.pos_in[i];
     }
     if (a.r_in) a.r_out[dst] = a.r_in[i];
-    if (a.u_in) a.u_out[dst] = a.u_in[i];
+    if (a.r2_in) a.r2_out[dst] = a.r2_in[i];
+    if (a.r3_in) a.r3_out[dst] = a.r3_in[i];
+    if (a.u_in) {
+        const uint32_t id = a.u_in[i];
+        a.u_out[dst] = id;
+        if (a.count_owned) {
+            const unsigned long long m = __ballot((id >> 31) != 0);
+            if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
+                atomicAdd(&a.count_owned->stripe[blockIdx.x % STRIPES].owned, (unsigned long long)__popcll(m));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ a, uint32_t n) {
@@ -396,6 +429,104 @@ __global__ __launch_bounds__(256) void k_unpack_vel(const float4* __restrict__ P
     const float4 pv = PV[i];
     vel[i] = make_float2(pv.z, pv.w);
 }
+// ---- multi-GPU tiles -------------------------------------------------------------------------------------------------
+// plain advect (dfsph.rs:499-510) for the tile path, where the halo exchange sits between the advection and the re-grid
+__global__ __launch_bounds__(256) void k_advect(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t n, float dt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 pv = PV[i];
+    pv.x = pv.x + pv.z * dt;
+    pv.y = pv.y + pv.w * dt;
+    PV[i] = pv;
+    posA[i] = make_float2(pv.x, pv.y);
+}
+// 32-byte halo record
+struct HaloRec {
+    float4 pv;
+    uint32_t id;
+    float kappa, stiff;
+    uint32_t pad;
+};
+// send-set flags: owned particles within `halo` cells of the left / right cut (particles that migrated across it included)
+__global__ __launch_bounds__(256) void k_tile_flags(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
+                                                     uint32_t halo, uint32_t* __restrict__ flag_l, uint32_t* __restrict__ flag_r) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 pv = PV[i];
+    const bool owned = (pid[i] >> 31) != 0 && pv.x == pv.x;
+    const uint32_t c = tile_coord(K, pv.x, pv.y);
+    flag_l[i] = (owned && c < K.tile_lo + halo) ? 1u : 0u;
+    flag_r[i] = (owned && c + halo >= K.tile_hi) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_tile_pack(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, const float* __restrict__ kappa,
+                                                    const float* __restrict__ stiff, const uint2* __restrict__ scan, uint32_t n,
+                                                    HaloRec* __restrict__ out, uint32_t cap) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint2 se = scan[i];
+    if (se.y == se.x || se.x >= cap) return;
+    HaloRec r;
+    r.pv = PV[i];
+    r.id = pid[i] & 0x7FFFFFFFu;
+    r.kappa = kappa[i];
+    r.stiff = stiff[i];
+    r.pad = 0;
+    out[1 + se.x] = r;  // record 0 is the header (count)
+}
+// particles that are no longer owned by this tile (ghosts of the previous step, particles that migrated out) vanish at the
+// next re-grid: a NaN position gets no cell
+__global__ __launch_bounds__(256) void k_tile_drop(float4* __restrict__ PV, float2* __restrict__ posA, const uint32_t* __restrict__ pid, uint32_t n,
+                                                    Consts K) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 pv = PV[i];
+    const bool keep = (pid[i] >> 31) != 0 && pv.x == pv.x && tile_owns(K, pv.x, pv.y);
+    if (!keep) {
+        const float nan = __uint_as_float(0x7FC00000u);
+        PV[i].x = nan;
+        posA[i].x = nan;
+    }
+}
+// append the received records behind the current particles; unused slots up to n_base + 2*cap are marked dropped
+__global__ __launch_bounds__(256) void k_tile_apply(const HaloRec* __restrict__ from_l, const HaloRec* __restrict__ from_r, uint32_t cap,
+                                                     uint32_t n_base, Consts K, uint32_t halo, float4* __restrict__ PV, float2* __restrict__ posA,
+                                                     uint32_t* __restrict__ pid, float* __restrict__ kappa, float* __restrict__ stiff,
+                                                     DevScalars* __restrict__ scal) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * cap) return;
+    const bool right = r >= cap;
+    const HaloRec* src = right ? from_r : from_l;
+    const uint32_t k = right ? r - cap : r;
+    uint32_t cnt = src ? src[0].id : 0u;  // header
+    if (cnt > cap) {
+        cnt = cap;
+        if (k == 0) atomicOr(&scal->flags, DF_BLOCK_CAP);  // halo buffer too small
+    }
+    const uint32_t dst = n_base + r;
+    const float nan = __uint_as_float(0x7FC00000u);
+    if (k >= cnt) {
+        PV[dst] = make_float4(nan, 0.0f, 0.0f, 0.0f);
+        posA[dst] = make_float2(nan, 0.0f);
+        pid[dst] = 0;
+        return;
+    }
+    const HaloRec rec = src[1 + k];
+    const uint32_t c = tile_coord(K, rec.pv.x, rec.pv.y);
+    const bool own = c >= K.tile_lo && c < K.tile_hi;
+    const bool ghost = c + halo >= K.tile_lo && c < K.tile_hi + halo;
+    float4 pv = rec.pv;
+    if (!own && !ghost) pv.x = nan;
+    PV[dst] = pv;
+    posA[dst] = make_float2(pv.x, pv.y);
+    pid[dst] = rec.id | (own ? 0x80000000u : 0u);
+    kappa[dst] = rec.kappa;
+    stiff[dst] = rec.stiff;
+}
+__global__ __launch_bounds__(256) void k_set_ids(uint32_t* __restrict__ pid, const uint32_t* __restrict__ ids, uint32_t n, uint32_t flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) pid[i] = (ids ? ids[i] : i) | flag;
+}
+
 // boundary tails of the [N|B] arrays: {bpos, 0, 0}
 __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ bpos, uint32_t nb, uint32_t soff, float2* __restrict__ posA,
                                                      float2* __restrict__ posA2, float4* __restrict__ PV, float4* __restrict__ PV2,
@@ -704,7 +835,7 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
         }
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
-        vsq = px * px + py * py;
+        vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
     // exact max: non-negative floats order like their bit patterns
     const uint32_t m = block_max_u32(__float_as_uint(vsq));
@@ -747,7 +878,7 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
                                                         float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
                                                         DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    float e = 0.0f;
+    float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
         const uint32_t c = counts[i];
         const uint32_t cd = c & 0xffffu, ct = c >> 16;
@@ -782,8 +913,9 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
         }
         PK[i] = make_float4(pvi.x, pvi.y, e * alpha[i], e);
         if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363, folded into the first iteration
+        e_owned = tile_owns(K, pvi.x, pvi.y) ? e : 0.0f;
     }
-    const double bs = block_sum_f64((double)e);
+    const double bs = block_sum_f64((double)e_owned);
     __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
         __hip_atomic_store((unsigned long long*)&partials[blockIdx.x], (unsigned long long)__double_as_longlong(bs), __ATOMIC_RELAXED,
@@ -901,8 +1033,14 @@ __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos,
 // publish the sticky flags / neighbour-entry count outside a solver step (sphx_update_neighborhood)
 __global__ void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {
     unsigned long long nb = 0;
-    for (uint32_t k = 0; k < STRIPES; ++k) nb += scal->stripe[k].nb_entries;
+    unsigned long long ow = 0;
+    for (uint32_t k = 0; k < STRIPES; ++k) {
+        nb += scal->stripe[k].nb_entries;
+        ow += scal->stripe[k].owned;
+    }
     mb->nb_entries = nb;
+    mb->owned_cum = ow;
+    mb->sort_total = scal->sort_total;
     mb->flags = scal->flags;
     __threadfence_system();
     __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1,0 +1,346 @@
+"""Spatial-tile (multi-GPU) driver of the DFSPH step — SURVEY.md §8(e), DESIGN.md §7.
+
+The reference (yasph2d) has no distributed path.  The domain is cut into strips along one axis at cell boundaries; rank r
+OWNS the particles whose cell coordinate lies in [cuts[r], cuts[r+1]) and additionally holds GHOST copies of the neighbours'
+particles within `halo` cells of its cuts.  One process per GPU; the only per-step collectives are
+
+  * one halo exchange (32-byte particle records, send/recv with the <= 2 spatial neighbours) between advect and re-grid:
+    it carries migration (particles that crossed a cut) and rebuilds the ghost set from scratch, and
+  * three tiny all-reduces: max |v + a dt|^2 (CFL, dfsph.rs:474-479) and the residual sum + owned count of every solver
+    iteration (dfsph.rs:221, :377).
+
+Ghost values are NOT exchanged per sub-step.  Every neighbour traversal makes the outermost still-valid ring of ghost cells
+invalid (a ghost's own neighbours are missing beyond the halo), so with a halo of H cells the driver has a budget of H rings
+between two exchanges; it tracks the budget (`_valid`) and inserts an extra exchange + re-grid only when a long solver loop
+would exhaust it.  The redundant work is H cells per cut (a few % of a tile), the latency of 6 exchanges per step is saved.
+
+The driver is backend-agnostic: `GpuTileBackend` (libsphx, the product) or the oracle-based backend of the CPU tests
+(tests/tile_oracle_backend.py) implement the same sub-step interface, and `TorchComm` runs over RCCL ("nccl") on GPUs and
+over gloo in the CPU tests.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import SphxError
+
+HALO_RECORD_BYTES = 32
+HALO_DTYPE = np.dtype([("pv", np.float32, 4), ("id", np.uint32), ("kappa", np.float32), ("stiff", np.float32), ("pad", np.uint32)])
+OWNED_BIT = np.uint32(0x80000000)
+
+
+def cell_coord(pos, axis, grid_min=-100.0, cell_inv=None, h=0.02):
+    """GridProperties::position_to_mortoncellpos (neighborhood_search.rs:52-58) along one axis, same f32 ops as the device."""
+    ci = np.float32(cell_inv) if cell_inv is not None else np.float32(1.0) / np.float32(h)
+    v = (pos[:, axis].astype(np.float32) - np.float32(grid_min)) * ci
+    return np.clip(np.nan_to_num(v, nan=0.0), 0.0, 65535.0).astype(np.uint32)
+
+
+def quantile_cuts(coords, world):
+    """Cut positions (cell indices) at particle-count quantiles; cuts[0] = 0, cuts[world] = 65536."""
+    s = np.sort(coords)
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(s[(len(s) * r) // world]))
+    cuts.append(65536)
+    for r in range(1, world + 1):  # strictly increasing
+        cuts[r] = max(cuts[r], cuts[r - 1] + 1)
+    return cuts
+
+
+# ------------------------------------------------------------------------------------------------------------ communicators
+class TorchComm:
+    """torch.distributed: backend "nccl" IS RCCL on ROCm (device tensors over xGMI); "gloo" in the CPU tests."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def exchange(self, send_left, send_right, recv_left, recv_right):
+        import torch.distributed as dist
+
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, send_left, self.rank - 1), dist.P2POp(dist.irecv, recv_left, self.rank - 1)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, send_right, self.rank + 1), dist.P2POp(dist.irecv, recv_right, self.rank + 1)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if self.device.type == "cuda":
+                import torch
+
+                torch.cuda.synchronize(self.device)
+
+    def allreduce_max(self, x):
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allreduce_sum(self, xs):
+        import torch
+
+        t = torch.tensor(list(xs), dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+
+class ThreadComm:
+    """In-process communicator: `world` tiles run as threads of one process (single-GPU tests of the tile path)."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [dict() for _ in range(world)]
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def exchange(self, send_left, send_right, recv_left, recv_right):
+        self.sh.slots[self.rank]["L"], self.sh.slots[self.rank]["R"] = send_left, send_right
+        self.sh.barrier.wait()
+        if self.rank > 0:
+            recv_left.copy_(self.sh.slots[self.rank - 1]["R"])
+        if self.rank < self.world - 1:
+            recv_right.copy_(self.sh.slots[self.rank + 1]["L"])
+        if recv_left.is_cuda:
+            import torch
+
+            torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
+    def _gather(self, x):
+        self.sh.slots[self.rank]["v"] = x
+        self.sh.barrier.wait()
+        vals = [self.sh.slots[r]["v"] for r in range(self.world)]
+        self.sh.barrier.wait()
+        return vals
+
+    def allreduce_max(self, x):
+        return max(self._gather(x))
+
+    def allreduce_sum(self, xs):
+        vals = self._gather(list(xs))
+        return [sum(v[k] for v in vals) for k in range(len(xs))]
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU backend
+class GpuTileBackend:
+    """The product path: one libsphx context per tile; halo buffers are torch device tensors handed to RCCL as they are."""
+
+    def __init__(self, ctx, device=None):
+        import torch
+
+        self.ctx = ctx
+        self.L = ctx.L
+        self.torch = torch
+        self.device = device if device is not None else torch.device("cuda", ctx.params.device)
+
+    def _chk(self, rc):
+        if rc:
+            raise SphxError(rc, self.L.sphx_last_error(self.ctx.h).decode())
+
+    def make_buffers(self, cap):
+        n = (1 + cap) * HALO_RECORD_BYTES
+        return [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(4)]
+
+    def set_boundary(self, xy):
+        self.ctx.set_boundary(xy)
+
+    def configure(self, axis, lo, hi, halo, has_left, has_right):
+        self._chk(self.L.sphx_tile_configure(self.ctx.h, axis, lo, hi, halo, int(has_left), int(has_right)))
+
+    def reserve(self, capacity):
+        self._chk(self.L.sphx_reserve(self.ctx.h, capacity))
+
+    def upload(self, pos, vel, ids):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.sphx_tile_upload(self.ctx.h, p(pos), p(vel), p(ids), len(pos)))
+
+    def pack(self, send_left, send_right, cap):
+        self._chk(self.L.sphx_tile_pack(self.ctx.h, C.c_void_p(send_left.data_ptr()), C.c_void_p(send_right.data_ptr()), cap))
+
+    def apply(self, recv_left, recv_right, cap):
+        self._chk(self.L.sphx_tile_apply(self.ctx.h, C.c_void_p(recv_left.data_ptr()) if recv_left is not None else None,
+                                         C.c_void_p(recv_right.data_ptr()) if recv_right is not None else None, cap))
+
+    def regrid(self):
+        n = C.c_uint32()
+        self._chk(self.L.sphx_sub_regrid(self.ctx.h, C.byref(n)))
+        return n.value
+
+    def nonpressure(self, dt_prev):
+        v = C.c_float()
+        self._chk(self.L.sphx_sub_nonpressure(self.ctx.h, dt_prev, C.byref(v)))
+        return v.value
+
+    def predict(self, dt):
+        self._chk(self.L.sphx_sub_predict(self.ctx.h, dt))
+
+    def warmstart(self, divergence, dt):
+        self._chk(self.L.sphx_sub_warmstart(self.ctx.h, int(divergence), dt))
+
+    def iteration(self, divergence, dt, first):
+        s, n = C.c_double(), C.c_uint64()
+        self._chk(self.L.sphx_sub_iteration(self.ctx.h, int(divergence), dt, int(first), C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def advect(self, dt):
+        self._chk(self.L.sphx_sub_advect(self.ctx.h, dt))
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def download(self):
+        d = self.ctx.download()
+        ss = self.ctx.download_solver_state()
+        ids = d["ids"]
+        return dict(pos=d["pos"], vel=d["vel"], density=d["density"], ids=ids & np.uint32(0x7FFFFFFF), owned=(ids >> np.uint32(31)) != 0,
+                    kappa=ss["kappa"], stiffness=ss["stiffness"], alpha=ss["alpha"])
+
+
+# -------------------------------------------------------------------------------------------------------------------- driver
+class TiledDFSPH:
+    """Solver::simulation_step (dfsph.rs:414-525) over spatial tiles.  All ranks call the same methods in lockstep."""
+
+    def __init__(self, backend, comm, axis, cuts, halo=16, cap_records=None, max_avg_density_error=np.float32(0.01) / np.float32(100.0),
+                 max_density_iterations=200, max_divergence_error=np.float32(0.1) / np.float32(100.0), max_divergence_iterations=400,
+                 fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0):
+        self.b, self.comm, self.axis, self.cuts, self.halo = backend, comm, axis, list(cuts), int(halo)
+        self.rank, self.world = comm.rank, comm.world
+        self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+        self.has_left, self.has_right = self.rank > 0, self.rank < self.world - 1
+        self.tol_d, self.max_d = np.float32(max_avg_density_error), int(max_density_iterations)
+        self.tol_v, self.max_v = np.float32(max_divergence_error), int(max_divergence_iterations)
+        self.fixed = fixed_iterations
+        self.rho0 = np.float32(fluid_density)
+        self.diam = np.float32(2.0) * np.float32(particle_radius)
+        self.h, self.grid_min = h, grid_min
+        self.num_density_iters, self.num_divergence_iters = 1, 0  # dfsph.rs:51,55
+        self.cap = cap_records
+        self.exchanges = 0
+        self._valid = self._kvalid = float("inf")
+
+    # ---- setup ------------------------------------------------------------------------------------------------------------
+    def setup(self, pos, vel, ids, boundary):
+        """All ranks pass the SAME global arrays (deterministic scene); each keeps its own cells."""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        vel = np.zeros_like(pos) if vel is None else np.ascontiguousarray(vel, np.float32).reshape(-1, 2)
+        ids = np.arange(len(pos), dtype=np.uint32) if ids is None else np.asarray(ids, np.uint32)
+        c = cell_coord(pos, self.axis, self.grid_min, h=self.h)
+        mine = (c >= self.lo) & (c < self.hi)
+        n_own = int(mine.sum())
+        if self.world > 1:
+            widths = [self.cuts[r + 1] - self.cuts[r] for r in range(1, self.world - 1)]
+            if any(w < 2 * self.halo for w in widths) or (self.world > 1 and min(self.hi, 65536) - self.lo < 2 * self.halo and 0 < self.rank < self.world - 1):
+                raise ValueError("tiles must be at least two halo widths wide")
+        if self.cap is None:
+            # particles within `halo` cells of a cut: estimate from the global scene, with head-room for compression waves
+            near = 0
+            for cut in self.cuts[1:-1]:
+                near = max(near, int(((c >= cut - self.halo) & (c < cut + self.halo)).sum()))
+            self.cap = max(1024, int(near * 1.5) + 1024)
+        self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
+        self.b.reserve(int(n_own * 1.25) + 4 * self.cap + 4096)
+        if boundary is not None and len(boundary):
+            bc = cell_coord(np.asarray(boundary, np.float32).reshape(-1, 2), self.axis, self.grid_min, h=self.h)
+            keep = (bc + (self.halo + 2) >= self.lo) & (bc < self.hi + self.halo + 2)
+            self.b.set_boundary(np.asarray(boundary, np.float32).reshape(-1, 2)[keep])
+        self.b.upload(pos[mine], vel[mine], ids[mine])
+        self.bufs = self.b.make_buffers(self.cap)
+        self.n_owned_global = len(pos)
+        self.refresh()  # initial ghosts + the warm-up block (dfsph.rs:419-428): re-grid, densities, alpha
+
+    # ---- halo ---------------------------------------------------------------------------------------------------------------
+    def refresh(self):
+        """Halo exchange (migration + fresh ghosts) followed by the re-grid of the local set."""
+        sl, sr, rl, rr = self.bufs
+        self.b.pack(sl, sr, self.cap)
+        self.comm.exchange(sl, sr, rl, rr)
+        self.b.apply(rl if self.has_left else None, rr if self.has_right else None, self.cap)
+        self.n_local = self.b.regrid()
+        self.exchanges += 1
+        full = float("inf") if self.world == 1 else float(self.halo)
+        self._valid = self._kvalid = full          # rings (cells from the owned region) in which v* / kappa are exact
+        self._avalid = full - 1                    # ... density and alpha (one traversal after the exchange)
+
+    def _need(self, after):
+        """Make sure the owned region stays exact after an operation that leaves `after` valid rings."""
+        if after < 0:
+            self.refresh()
+            return True
+        return False
+
+    # ---- one step -----------------------------------------------------------------------------------------------------------
+    def _loop(self, divergence, dt):
+        prev = self.num_divergence_iters if divergence else self.num_density_iters
+        fixed = self.fixed[1] if divergence else self.fixed[0]
+        tol, cap = (self.tol_v, self.max_v) if divergence else (self.tol_d, self.max_d)
+        warm = 0
+        if prev > 1:  # dfsph.rs:199 / :354
+            if self._need(min(self._valid, self._kvalid - 1)):
+                pass
+            self.b.warmstart(divergence, dt)
+            self._valid = min(self._valid, self._kvalid - 1)
+            warm = 1
+        iters, avg = 0, np.float32(0)
+        while True:
+            self._need(min(self._valid - 2, self._avalid - 1))
+            kvalid = min(self._valid - 1, self._avalid)
+            s, n_owned = self.b.iteration(divergence, dt, iters == 0)
+            self._valid = min(self._valid - 2, self._avalid - 1)
+            self._kvalid = kvalid
+            iters += 1
+            S, N = self.comm.allreduce_sum([s, float(n_owned)])
+            self.n_owned_global = int(N)
+            avg = np.float32(np.float32(S) / np.float32(N))
+            if divergence:
+                avg = np.float32(avg / self.rho0)  # dfsph.rs:376-377
+            if not np.isfinite(avg):
+                raise SphxError(_lib.ERR_NONFINITE, "residual is not finite (dfsph.rs:223,378)")
+            if fixed:
+                if iters >= fixed:
+                    break
+                continue
+            rel = avg if divergence else np.float32(avg / self.rho0)  # dfsph.rs:222
+            if np.float32(rel * np.float32(dt)) < tol:               # dfsph.rs:226 / :381
+                break
+            if iters > cap:                                          # dfsph.rs:236 / :391
+                break
+        if divergence:
+            self.num_divergence_iters = iters
+        else:
+            self.num_density_iters = iters
+        return iters, float(avg), warm
+
+    def step(self, timer):
+        """One simulation_step; `timer` mirrors TimeManager (yasph2d_amd.TimeManager); identical on every rank."""
+        from . import duration_as_secs_f32
+
+        dt_prev = timer.simulation_step()
+        self._need(min(self._avalid, self._valid) - 1)
+        vsq = self.b.nonpressure(dt_prev)                                   # dfsph.rs:436-477
+        vmax = float(np.sqrt(np.float32(self.comm.allreduce_max(float(vsq)))))
+        dt_ns = timer.update_simulation_step(self.diam, vmax)               # dfsph.rs:478-480
+        dt = duration_as_secs_f32(dt_ns)
+        self.b.predict(dt)                                                  # dfsph.rs:484-492
+        self._valid = min(self._avalid, self._valid) - 1
+        Id, avg_d, wd = self._loop(False, dt)                               # dfsph.rs:496
+        self.b.advect(dt)                                                   # dfsph.rs:499-510 (ghosts move with their exact copies' v*)
+        self.refresh()                                                      # migration + ghosts, dfsph.rs:512-518
+        Iv, avg_v, wv = self._loop(True, dt)                                # dfsph.rs:521
+        return dict(density_iterations=Id, divergence_iterations=Iv, warmstart_density=wd, warmstart_divergence=wv, avg_density_error=avg_d,
+                    avg_divergence=avg_v, dt_prev=dt_prev, dt=dt, vmax=vmax, dt_ns=dt_ns, n_local=self.n_local, n_global=self.n_owned_global)
+
+    def download_owned(self):
+        d = self.b.download()
+        m = d["owned"]
+        return {k: (v[m] if hasattr(v, "__len__") and len(v) == len(m) else v) for k, v in d.items()}
