@@ -59,32 +59,46 @@ class TorchComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
     def exchange(self, send_left, send_right, recv_left, recv_right):
+        import torch
         import torch.distributed as dist
 
+        # gloo cannot send device tensors: stage through the host (functional tests on a single-GPU box); RCCL sends the
+        # device buffers as they are.
+        stage = dist.get_backend() == "gloo" and send_left.is_cuda
+        sl, sr = (send_left.cpu(), send_right.cpu()) if stage else (send_left, send_right)
+        rl, rr = (torch.empty_like(sl), torch.empty_like(sr)) if stage else (recv_left, recv_right)
         ops = []
         if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, send_left, self.rank - 1), dist.P2POp(dist.irecv, recv_left, self.rank - 1)]
+            ops += [dist.P2POp(dist.isend, sl, self.rank - 1), dist.P2POp(dist.irecv, rl, self.rank - 1)]
         if self.rank < self.world - 1:
-            ops += [dist.P2POp(dist.isend, send_right, self.rank + 1), dist.P2POp(dist.irecv, recv_right, self.rank + 1)]
+            ops += [dist.P2POp(dist.isend, sr, self.rank + 1), dist.P2POp(dist.irecv, rr, self.rank + 1)]
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-            if self.device.type == "cuda":
-                import torch
+            if stage:
+                if self.rank > 0:
+                    recv_left.copy_(rl)
+                if self.rank < self.world - 1:
+                    recv_right.copy_(rr)
+            if send_left.is_cuda:
+                torch.cuda.synchronize(send_left.device)
 
-                torch.cuda.synchronize(self.device)
+    def _red_device(self):
+        import torch
+
+        return torch.device("cpu") if self.dist.get_backend() == "gloo" else self.device
 
     def allreduce_max(self, x):
         import torch
 
-        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        t = torch.tensor([x], dtype=torch.float64, device=self._red_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def allreduce_sum(self, xs):
         import torch
 
-        t = torch.tensor(list(xs), dtype=torch.float64, device=self.device)
+        t = torch.tensor(list(xs), dtype=torch.float64, device=self._red_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(v) for v in t.tolist()]
 
