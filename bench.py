@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
+    ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
     timer = y.TimeManager()
     ctx = y.SphxContext(y.default_params(device=dev_index))
 
-    if world == 1:
+    if world == 1 and not args.force_tiles:
         ctx.set_boundary(boundary)
         ctx.upload(pos)
         n = n_global
@@ -118,8 +119,13 @@ def main():
         ext = pos.max(0) - pos.min(0)
         axis = int(ext[1] > ext[0])
         cuts = quantile_cuts(cell_coord(pos, axis), world)
-        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), TorchComm(dist, torch.device("cuda", dev_index)), axis, cuts,
-                           halo=args.halo)
+        if dist is not None:
+            comm = TorchComm(dist, torch.device("cuda", dev_index))
+        else:
+            from yasph2d_amd.tiles import ThreadComm
+
+            comm = ThreadComm(ThreadComm.Shared(1), 0)
+        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, axis, cuts, halo=args.halo)
         tiled.setup(pos, None, None, boundary)
         n = n_global // world
 
@@ -153,7 +159,7 @@ def main():
     Iv = float(np.mean([s["divergence_iterations"] for s in stats]))
     Wd = float(np.mean([s["warmstart_density"] for s in stats]))
     Wv = float(np.mean([s["warmstart_divergence"] for s in stats]))
-    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n if world == 1 else None
+    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n if tiled is None else None
 
     roof = None
     if not args.no_roofline:
@@ -196,7 +202,7 @@ def main():
                             f"in total ({n} fluid per GPU), adaptive CFL timer from t=0, two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "particles_total": n_global,
-                "parallelism": "single GPU" if world == 1 else
+                "parallelism": "single GPU" if tiled is None else
                 f"{world} spatial strips along {'xy'[tiled.axis]} cut at particle-count quantiles, {args.halo}-cell ghost halo, per step: 1 halo "
                 f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces; {tiled.exchanges} exchanges in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,

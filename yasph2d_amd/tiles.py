@@ -260,7 +260,7 @@ class TiledDFSPH:
             # particles within `halo` cells of a cut: estimate from the global scene, with head-room for compression waves
             near = 0
             for cut in self.cuts[1:-1]:
-                near = max(near, int(((c >= cut - self.halo) & (c < cut + self.halo)).sum()))
+                near = max(near, int(((c >= cut - self.halo) & (c < cut)).sum()), int(((c >= cut) & (c < cut + self.halo)).sum()))
             self.cap = max(1024, int(near * 1.5) + 1024)
         self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
         self.b.reserve(int(n_own * 1.25) + 4 * self.cap + 4096)
