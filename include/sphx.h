@@ -34,7 +34,7 @@ enum {
     SPHX_ERR_NOT_READY = 4,       /* step called before upload / begin-finish out of order */
     SPHX_ERR_NONFINITE = 5,       /* dfsph.rs:223,378 assert!(avg.is_finite()) */
     SPHX_ERR_NEIGHBOR_PANIC = 6,  /* neighborhood_search.rs:373: 64 dynamic neighbours and a static hit (reference panics) */
-    SPHX_ERR_CAPACITY = 7,        /* internal table capacity exceeded (grid blocks / neighbour entries) */
+    SPHX_ERR_CAPACITY = 7,        /* a capacity was exceeded (halo exchange buffer, sphx_reserve, 2^32 table entries) */
     SPHX_ERR_OUT_OF_DOMAIN = 8    /* a particle left the Morton domain the grid tables were sized for */
 };
 

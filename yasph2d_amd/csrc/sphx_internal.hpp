@@ -24,7 +24,7 @@ constexpr uint32_t WIN_HALO = 256;      // neighbour build: positions of [block_
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_BLOCK_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
 struct Consts {

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_tile_apply(const HaloRec* __restrict__ 
     uint32_t cnt = src ? src[0].id : 0u;  // header
     if (cnt > cap) {
         cnt = cap;
-        if (k == 0) atomicOr(&scal->flags, DF_BLOCK_CAP);  // halo buffer too small
+        if (k == 0) atomicOr(&scal->flags, DF_HALO_CAP);  // halo buffer too small
     }
     const uint32_t dst = n_base + r;
     const float nan = __uint_as_float(0x7FC00000u);
