@@ -1,0 +1,153 @@
+"""Edge cases of the path on the GPU, each against the oracle: particle-count changes mid-run (the reference's resize keeps
+the slot-bound warm-start values, dfsph.rs:419-428), boundary replaced mid-run, static neighbours next to the 64 cap, fixed
+time step, error codes for non-finite input, and a long violent run with warm starts and many solver iterations."""
+import numpy as np
+import pytest
+from util import assert_bits_equal, assert_same_neighbors, dam_break
+
+import yasph2d_amd as y
+from oracle.oracle import Oracle
+from yasph2d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(pos, boundary=None, vel=None):
+    ctx, o = y.SphxContext(), Oracle()
+    if boundary is not None:
+        ctx.set_boundary(boundary)
+        o.set_boundary(boundary)
+    ctx.upload(pos, vel)
+    o.set_particles(pos, vel)
+    return ctx, o
+
+
+def step_both(ctx, o, timer, check=True):
+    vmax = ctx.step_begin(timer.simulation_step())
+    dt_ns = timer.update_simulation_step(np.float32(0.01), vmax)
+    st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+    so = o.dfsph_step()
+    if check:
+        assert dt_ns == o.timer_step_ns()
+        for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence"):
+            assert st[k] == so[k], (k, st[k], so[k])
+    return st, so
+
+
+def compare_state(ctx, o, what=""):
+    d = ctx.download()
+    assert_bits_equal(d["pos"], o.positions(), what + " positions")
+    assert_bits_equal(d["vel"], o.velocities(), what + " velocities")
+    assert_bits_equal(d["density"], o.densities(), what + " densities")
+    ss = ctx.download_solver_state()
+    assert_bits_equal(ss["kappa"], o.kappa(), what + " kappa")
+    assert_bits_equal(ss["stiffness"], o.stiffness(), what + " stiffness")
+    assert_same_neighbors(ctx.download_neighbors(), o.neighbors())
+
+
+def test_violent_phase_with_warm_starts():
+    """900 adaptive steps of the reference scene: impact, splash-up, many steps with Iv > 1 and warm starts."""
+    pos, boundary = dam_break(1.0)
+    ctx, o = pair(pos, boundary)
+    timer = y.TimeManager()
+    warm = multi = 0
+    for s in range(900):
+        st, _ = step_both(ctx, o, timer)
+        warm += st["warmstart_density"] + st["warmstart_divergence"]
+        multi += (st["density_iterations"] > 1) + (st["divergence_iterations"] > 1)
+        if s % 150 == 149:
+            compare_state(ctx, o, f"step {s}")
+    assert warm > 20 and multi > 20, (warm, multi)
+    compare_state(ctx, o, "final")
+
+
+def test_adding_particles_mid_run_keeps_slot_bound_warm_start_values():
+    """add_fluid_rect during the run (count changes -> warm-up block again, Vec::resize keeps old entries, dfsph.rs:420-422)."""
+    w = y.FluidParticleWorld()
+    w.reset_fluid(1.0)
+    pos, boundary = w.positions, w.boundary_particles
+    ctx, o = pair(pos, boundary)
+    timer = y.TimeManager()
+    for _ in range(150):  # through the impact so that kappa / stiffness are non-zero
+        step_both(ctx, o, timer)
+    assert np.abs(ctx.download_solver_state()["stiffness"]).max() > 0
+    # the application appends a block of fluid to the (sorted) arrays it got back
+    d = ctx.download()
+    extra = (np.array([1.2, 1.0], np.float32) + np.stack(np.meshgrid(np.arange(20), np.arange(20)), -1).reshape(-1, 2).astype(np.float32) * np.float32(0.0111)).astype(np.float32)
+    new_pos = np.concatenate([d["pos"], extra])
+    new_vel = np.concatenate([d["vel"], np.zeros_like(extra)])
+    ctx.upload(new_pos, new_vel)
+    o.set_particles(new_pos, new_vel)
+    for _ in range(40):
+        st, _ = step_both(ctx, o, timer)
+    compare_state(ctx, o, "after growth")
+
+
+def test_boundary_replaced_mid_run():
+    pos, boundary = dam_break(1.0)
+    ctx, o = pair(pos, boundary)
+    timer = y.TimeManager()
+    for _ in range(20):
+        step_both(ctx, o, timer)
+    b2 = boundary[boundary[:, 1] < 2.0]  # drop the lid: boundary_changed = true (fluidparticleworld.rs:194)
+    ctx.set_boundary(b2)
+    o.set_boundary(b2)
+    for _ in range(20):
+        step_both(ctx, o, timer)
+    compare_state(ctx, o, "after boundary change")
+    bxy, _ = ctx.download_boundary()
+    assert_bits_equal(bxy, o.boundary(), "sorted boundary")
+
+
+def test_fixed_time_step():
+    pos, boundary = dam_break(1.0)
+    ctx, o = pair(pos, boundary)
+    timer = y.TimeManager(fixed_ns=500_000)  # SimulationStepConfig::FixedTimeStep (timemanager.rs:40)
+    o.timer_fixed(500_000)
+    for _ in range(60):
+        step_both(ctx, o, timer)
+    compare_state(ctx, o, "fixed dt")
+
+
+def test_dense_blob_next_to_a_wall_hits_the_neighbor_cap():
+    """~90 particles within one radius next to boundary particles: dynamic lists are capped at 64 and the reference would panic on
+    the first static hit (neighborhood_search.rs:373) -> SPHX_ERR_NEIGHBOR_PANIC, not a crash."""
+    rng = np.random.default_rng(4)
+    pos = (np.array([0.5, 0.5], np.float32) + rng.random((90, 2), dtype=np.float32) * np.float32(0.012)).astype(np.float32)
+    wall = np.stack([np.linspace(0.49, 0.53, 9, dtype=np.float32), np.full(9, 0.495, np.float32)], -1)
+    ctx = y.SphxContext()
+    ctx.set_boundary(wall)
+    ctx.upload(pos)
+    with pytest.raises(y.SphxError) as e:
+        ctx.update_neighborhood()
+    assert e.value.code == _lib.ERR_NEIGHBOR_PANIC
+    # without the wall: capped lists, flag only
+    ctx2, o2 = pair(pos)
+    ctx2.update_neighborhood()
+    o2.update_neighborhood()
+    assert_same_neighbors(ctx2.download_neighbors(), o2.neighbors())
+    assert o2.neighbor_flags() & 1
+
+
+def test_nonfinite_velocity_is_an_error_code():
+    pos, boundary = dam_break(1.0)
+    vel = np.zeros_like(pos)
+    vel[17] = [np.inf, 0.0]
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos, vel)
+    with pytest.raises(y.SphxError) as e:
+        ctx.step_begin(1e-4)
+    assert e.value.code == _lib.ERR_NONFINITE  # Duration::from_secs_f32 would panic (timemanager.rs:264)
+
+
+def test_two_contexts_are_independent():
+    pos, boundary = dam_break(1.0)
+    a, oa = pair(pos, boundary)
+    b, ob = pair(pos[::2].copy(), boundary)
+    ta, tb = y.TimeManager(), y.TimeManager()
+    for _ in range(10):
+        step_both(a, oa, ta)
+        step_both(b, ob, tb)
+    compare_state(a, oa, "ctx a")
+    compare_state(b, ob, "ctx b")
