@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
+    ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
+                    help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -113,14 +115,17 @@ def main():
 
         tiled = None
     else:
-        from yasph2d_amd.tiles import GpuTileBackend, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+        from yasph2d_amd.tiles import GpuTileBackend, ShmComm, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
 
         # strips across the longer side of the fluid, cut at particle-count quantiles (equal particles per GPU)
         ext = pos.max(0) - pos.min(0)
         axis = int(ext[1] > ext[0])
         cuts = quantile_cuts(cell_coord(pos, axis), world)
         if dist is not None:
-            comm = TorchComm(dist, torch.device("cuda", dev_index))
+            if args.scalar_comm == "shm":
+                comm = ShmComm(dist, torch.device("cuda", dev_index), "bench" + os.environ.get("MASTER_PORT", "0"))
+            else:
+                comm = TorchComm(dist, torch.device("cuda", dev_index))
         else:
             from yasph2d_amd.tiles import ThreadComm
 
@@ -213,7 +218,7 @@ def main():
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
                 f"{world} spatial strips along {'xy'[tiled.axis]} cut at particle-count quantiles, {args.halo}-cell ghost halo, per step: 1 halo "
-                f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces; {tiled.exchanges} exchanges in total",
+                f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
             },
             "step_model": {"bytes_per_particle_step": bstep,

@@ -166,6 +166,17 @@ int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* df
 int sphx_sub_iteration(sphx_ctx* ctx, int divergence, float dt, int first, double* out_err_sum, uint64_t* out_n_owned); /* :217-221 / :372-377 */
 int sphx_sub_advect(sphx_ctx* ctx, float dt);                              /* dfsph.rs:499-510 */
 
+
+/* ---- single-node scalar reductions through POSIX shared memory ---------------------------------------------------------------
+ * The three per-step scalars of the tile driver (vmax, two residual sums) already sit in host memory (pinned mailbox) on every
+ * rank; for one process per GPU on ONE node a shared-memory all-reduce costs ~1 us instead of a device round trip through
+ * RCCL.  RCCL is used where the path really exchanges data (the halo records).  name: unique per job (e.g. MASTER_PORT). */
+typedef struct sphx_shm sphx_shm;
+sphx_shm* sphx_shm_open(const char* name, int rank, int world);
+/* op: 0 = sum, 1 = max; n <= 8 doubles; every rank gets the same bits (ranks are combined in rank order) */
+int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out);
+void sphx_shm_close(sphx_shm* h);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 int sphx_synchronize(sphx_ctx* ctx);
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream; totals are kept per kernel name. */

@@ -109,13 +109,15 @@ import numpy as np
 sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
 import torch, torch.distributed as dist
 import yasph2d_amd as y
-from yasph2d_amd.tiles import TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+from yasph2d_amd.tiles import ShmComm, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
 from tile_oracle_backend import OracleTileBackend
 from util import dam_break
 dist.init_process_group("gloo")
 pos, boundary = dam_break(1.0)
 cuts = quantile_cuts(cell_coord(pos, 1), dist.get_world_size())
-t = TiledDFSPH(OracleTileBackend(), TorchComm(dist, torch.device("cpu")), 1, cuts, halo=16)
+comm = (ShmComm(dist, torch.device("cpu"), "t" + os.environ["MASTER_PORT"]) if os.environ["COMM"] == "shm"
+        else TorchComm(dist, torch.device("cpu")))
+t = TiledDFSPH(OracleTileBackend(), comm, 1, cuts, halo=16)
 t.setup(pos, None, None, boundary)
 timer = y.TimeManager()
 stats = [t.step(timer) for _ in range(int(os.environ["STEPS"]))]
@@ -126,14 +128,16 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_tiles_gloo_world_size_2(tmp_path):
-    """The N > 1 launch path of bench.py: one process per rank, torch.distributed (gloo here, RCCL on the GPUs)."""
+@pytest.mark.parametrize("comm", ["torch", "shm"])
+def test_tiles_gloo_world_size_2(tmp_path, comm):
+    """The N > 1 launch path of bench.py: one process per rank, torch.distributed (gloo here, RCCL on the GPUs); scalars over
+    torch.distributed or over the shared-memory all-reduce (bench.py's default)."""
     import subprocess
 
     steps = 40
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)
-    env = dict(os.environ, REPO_ROOT=os.path.dirname(HERE), OUT_DIR=str(tmp_path), STEPS=str(steps), OMP_NUM_THREADS="1")
+    env = dict(os.environ, REPO_ROOT=os.path.dirname(HERE), OUT_DIR=str(tmp_path), STEPS=str(steps), OMP_NUM_THREADS="1", COMM=comm)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                            "--master-port", "29531", str(script)], env=env, timeout=600)
     pos, boundary = dam_break(1.0)
@@ -147,3 +151,50 @@ def test_tiles_gloo_world_size_2(tmp_path):
     for p in parts:
         assert int(p["dt_ns"][-1]) == timer_ns
         np.testing.assert_array_equal(p["Id"], [s["density_iterations"] for s in rstats])
+
+
+def _shm_worker(rank, world, name, q):
+    import ctypes as C
+
+    from yasph2d_amd import _lib
+
+    L = _lib.lib()
+    h = L.sphx_shm_open(name.encode(), rank, world)
+    assert h
+    buf_in, buf_out = (C.c_double * 8)(), (C.c_double * 8)()
+    res = []
+    for it in range(2000):
+        buf_in[0] = float(rank * 1000 + it)
+        buf_in[1] = 0.1 * (rank + 1) + it
+        assert L.sphx_shm_allreduce(h, buf_in, 2, it & 1, buf_out) == 0
+        res.append((buf_out[0], buf_out[1]))
+    L.sphx_shm_close(h)
+    q.put((rank, res))
+
+
+def test_shm_allreduce_four_processes():
+    """sphx_shm_allreduce: every rank gets identical bits, combined in rank order, for 2000 back-to-back rounds of alternating ops."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    world, name = 4, f"pytest{os.getpid()}"
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shm_worker, args=(r, world, name, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for it in range(2000):
+        a = [float(r * 1000 + it) for r in range(world)]
+        b = [0.1 * (r + 1) + it for r in range(world)]
+        if it & 1:
+            want = (max(a), max(b))
+        else:
+            sa, sb = a[0], b[0]
+            for r in range(1, world):
+                sa, sb = sa + a[r], sb + b[r]
+            want = (sa, sb)
+        for r in range(world):
+            assert got[r][it] == want

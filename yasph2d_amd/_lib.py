@@ -101,6 +101,9 @@ SIGNATURES = {
     "sphx_sub_warmstart": (_i, [_vp, _i, _f]),
     "sphx_sub_iteration": (_i, [_vp, _i, _f, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "sphx_sub_advect": (_i, [_vp, _f]),
+    "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
+    "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sphx_shm_close": (None, [_vp]),
     "sphx_synchronize": (_i, [_vp]),
     "sphx_profile_enable": (_i, [_vp, _i]),
     "sphx_profile_reset": (_i, [_vp]),

@@ -1,9 +1,17 @@
 // sphx_host.cpp — implementation of the host-side mirror (sphx_host.hpp) and its C exports (include/sphx.h, bottom half).
 #include "sphx_host.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace sph {
 
@@ -385,5 +393,116 @@ int sphx_solver_simulation_step(sphx_solver* s, sphx_world* w, sphx_timer* t, in
 int sphx_solver_sync_world(sphx_solver* s, sphx_world* w) { return s->s.sync_world(w->w); }
 sphx_ctx* sphx_solver_ctx(sphx_solver* s) { return s->s.ctx(); }
 const char* sphx_solver_last_error(const sphx_solver* s) { return s->s.last_error.c_str(); }
+
+}  // extern "C"
+
+// =====================================================================================================================
+// single-node scalar all-reduce through POSIX shared memory (tile driver)
+// =====================================================================================================================
+namespace {
+constexpr int SHM_MAX_WORLD = 64;
+constexpr int SHM_MAX_N = 8;
+struct ShmSegment {
+    std::atomic<uint32_t> magic;
+    std::atomic<uint32_t> attached;
+    std::atomic<uint64_t> arrive;  // total arrivals over all epochs
+    double slots[2][SHM_MAX_WORLD][SHM_MAX_N];
+};
+}  // namespace
+struct sphx_shm {
+    ShmSegment* seg = nullptr;
+    int rank = 0, world = 1;
+    uint64_t epoch = 0;
+    std::string name;
+};
+
+extern "C" {
+
+sphx_shm* sphx_shm_open(const char* name, int rank, int world) {
+    if (!name || rank < 0 || world < 1 || rank >= world || world > SHM_MAX_WORLD) return nullptr;
+    std::string nm = std::string("/sphx_") + name;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(nm.c_str());
+        fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(ShmSegment)) != 0) {
+            if (fd >= 0) close(fd);
+            return nullptr;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((fd = shm_open(nm.c_str(), O_RDWR, 0600)) < 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return nullptr;
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+        struct stat st;
+        while (fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(ShmSegment)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                close(fd);
+                return nullptr;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    }
+    void* p = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return nullptr;
+    sphx_shm* h = new sphx_shm();
+    h->seg = (ShmSegment*)p;
+    h->rank = rank;
+    h->world = world;
+    h->name = nm;
+    if (rank == 0) {
+        h->seg->arrive.store(0);
+        h->seg->attached.store(0);
+        h->seg->magic.store(0x53504858u, std::memory_order_release);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (h->seg->magic.load(std::memory_order_acquire) != 0x53504858u) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                munmap(p, sizeof(ShmSegment));
+                delete h;
+                return nullptr;
+            }
+            std::this_thread::yield();
+        }
+    }
+    h->seg->attached.fetch_add(1);
+    return h;
+}
+
+int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out) {
+    if (!h || !in || !out || n < 1 || n > SHM_MAX_N) return SPHX_ERR_INVALID_ARGUMENT;
+    ShmSegment* s = h->seg;
+    const int buf = (int)(h->epoch & 1);
+    for (int k = 0; k < n; ++k) s->slots[buf][h->rank][k] = in[k];
+    h->epoch += 1;
+    const uint64_t target = h->epoch * (uint64_t)h->world;
+    s->arrive.fetch_add(1, std::memory_order_acq_rel);
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (s->arrive.load(std::memory_order_acquire) < target) {
+        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) return SPHX_ERR_NOT_READY;
+        __builtin_ia32_pause();
+    }
+    for (int k = 0; k < n; ++k) {
+        double acc = s->slots[buf][0][k];
+        for (int r = 1; r < h->world; ++r) {
+            const double v = s->slots[buf][r][k];
+            acc = op == 1 ? (v > acc ? v : acc) : acc + v;
+        }
+        out[k] = acc;
+    }
+    return SPHX_OK;
+}
+
+void sphx_shm_close(sphx_shm* h) {
+    if (!h) return;
+    if (h->seg) {
+        munmap(h->seg, sizeof(ShmSegment));
+        if (h->rank == 0) shm_unlink(h->name.c_str());
+    }
+    delete h;
+}
 
 }  // extern "C"

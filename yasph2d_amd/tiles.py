@@ -103,6 +103,45 @@ class TorchComm:
         return [float(v) for v in t.tolist()]
 
 
+class ShmComm(TorchComm):
+    """One node, one process per GPU: halo records over torch.distributed (RCCL), the per-step scalars over a POSIX
+    shared-memory all-reduce in libsphx (they already sit in host memory on every rank; ~1 us instead of a device round trip)."""
+
+    def __init__(self, dist, device, name):
+        super().__init__(dist, device)
+        self.L = _lib.lib()
+        # rank 0 replaces any stale segment of that name before the others attach
+        self.h = self.L.sphx_shm_open(str(name).encode(), 0, self.world) if self.rank == 0 else None
+        dist.barrier()
+        if self.rank != 0:
+            self.h = self.L.sphx_shm_open(str(name).encode(), self.rank, self.world)
+        if not self.h:
+            raise RuntimeError("sphx_shm_open failed")
+        dist.barrier()
+        self._in = (C.c_double * 8)()
+        self._out = (C.c_double * 8)()
+
+    def _reduce(self, xs, op):
+        n = len(xs)
+        for k, v in enumerate(xs):
+            self._in[k] = v
+        rc = self.L.sphx_shm_allreduce(self.h, self._in, n, op, self._out)
+        if rc:
+            raise SphxError(rc, "shared-memory all-reduce timed out")
+        return [self._out[k] for k in range(n)]
+
+    def allreduce_max(self, x):
+        return self._reduce([x], 1)[0]
+
+    def allreduce_sum(self, xs):
+        return self._reduce(list(xs), 0)
+
+    def close(self):
+        if self.h:
+            self.L.sphx_shm_close(self.h)
+            self.h = None
+
+
 class ThreadComm:
     """In-process communicator: `world` tiles run as threads of one process (single-GPU tests of the tile path)."""
 
