@@ -71,7 +71,10 @@ class OracleTileBackend:
         pos, vel, ids, kappa, stiff = self._state()
         owned = (ids >> np.uint32(31)) != 0
         c = cell_coord(pos, self.axis)
-        keep = owned & (c >= self.lo) & (c < self.hi)
+        own = owned & (c >= self.lo) & (c < self.hi)
+        # owned particles that crossed a cut stay as ghosts while they are inside the ghost band (k_tile_drop)
+        keep = own | (owned & (c + self.halo >= self.lo) & (c < self.hi + self.halo))
+        ids = np.where(own, ids, ids & np.uint32(0x7FFFFFFF)).astype(np.uint32)
         parts = [(pos[keep], vel[keep], ids[keep], kappa[keep], stiff[keep])]
         for buf in (recv_left, recv_right):
             if buf is None:

@@ -473,19 +473,27 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float4* __restrict__ PV
     r.pad = 0;
     out[1 + se.x] = r;  // record 0 is the header (count)
 }
-// particles that are no longer owned by this tile (ghosts of the previous step, particles that migrated out) vanish at the
-// next re-grid: a NaN position gets no cell
-__global__ __launch_bounds__(256) void k_tile_drop(float4* __restrict__ PV, float2* __restrict__ posA, const uint32_t* __restrict__ pid, uint32_t n,
-                                                    Consts K) {
+// Ghosts of the previous step vanish at the next re-grid (a NaN position gets no cell); so do owned particles that left the
+// tile AND its ghost band.  An owned particle that crossed a cut but is still inside the ghost band stays as a ghost: the new
+// owner receives the very same record in this exchange but cannot send it back before the next one.
+__global__ __launch_bounds__(256) void k_tile_drop(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid, uint32_t n,
+                                                    Consts K, uint32_t halo) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 pv = PV[i];
-    const bool keep = (pid[i] >> 31) != 0 && pv.x == pv.x && tile_owns(K, pv.x, pv.y);
-    if (!keep) {
-        const float nan = __uint_as_float(0x7FC00000u);
-        PV[i].x = nan;
-        posA[i].x = nan;
+    const uint32_t id = pid[i];
+    const bool valid = (id >> 31) != 0 && pv.x == pv.x;
+    const uint32_t c = tile_coord(K, pv.x, pv.y);
+    const bool own = c >= K.tile_lo && c < K.tile_hi;
+    const bool ghost = c + halo >= K.tile_lo && c < K.tile_hi + halo;
+    if (valid && own) return;
+    if (valid && ghost) {
+        pid[i] = id & 0x7FFFFFFFu;
+        return;
     }
+    const float nan = __uint_as_float(0x7FC00000u);
+    PV[i].x = nan;
+    posA[i].x = nan;
 }
 // append the received records behind the current particles; unused slots up to n_base + 2*cap are marked dropped
 __global__ __launch_bounds__(256) void k_tile_apply(const HaloRec* __restrict__ from_l, const HaloRec* __restrict__ from_r, uint32_t cap,

@@ -51,6 +51,32 @@ def quantile_cuts(coords, world):
 
 
 # ------------------------------------------------------------------------------------------------------------ communicators
+def rebalance_cuts(cuts, counts, halo, columns, max_shift, threshold=1.05):
+    """Diffusive re-partition ("re-partition when max/mean load > ~1.1"): every interior cut moves towards the
+    heavier of its two tiles by half their difference expressed in cell columns (`columns` = mean particles per column), at
+    most `max_shift` cells (<= halo: the band that changes owner is already present as ghosts on the other side), and never
+    below two halo widths per tile.  Pure function of rank-identical inputs, so every rank computes the same cuts."""
+    W = len(counts)
+    mean = sum(counts) / max(W, 1)
+    if W < 2 or mean <= 0 or max(counts) <= threshold * mean:
+        return list(cuts)
+    new = list(cuts)
+    for r in range(1, W):
+        d = int(round((counts[r] - counts[r - 1]) * 0.5 / max(columns, 1.0)))
+        new[r] = cuts[r] + max(-max_shift, min(max_shift, d))
+    min_w = 2 * halo + 2
+    for r in range(1, W):          # left to right: keep every tile wide enough
+        lo_lim = new[r - 1] + min_w if r > 1 else new[r]
+        new[r] = max(new[r], lo_lim)
+    for r in range(W - 1, 0, -1):  # and right to left
+        hi_lim = new[r + 1] - min_w if r < W - 1 else new[r]
+        new[r] = min(new[r], hi_lim)
+    for r in range(1, W):          # a cut that the width rule pushed further than max_shift stays where it was
+        if abs(new[r] - cuts[r]) > max_shift:
+            return list(cuts)
+    return new
+
+
 class TorchComm:
     """torch.distributed: backend "nccl" IS RCCL on ROCm (device tensors over xGMI); "gloo" in the CPU tests."""
 
@@ -266,7 +292,7 @@ class TiledDFSPH:
 
     def __init__(self, backend, comm, axis, cuts, halo=16, cap_records=None, max_avg_density_error=np.float32(0.01) / np.float32(100.0),
                  max_density_iterations=200, max_divergence_error=np.float32(0.1) / np.float32(100.0), max_divergence_iterations=400,
-                 fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0):
+                 fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0, rebalance_every=0):
         self.b, self.comm, self.axis, self.cuts, self.halo = backend, comm, axis, list(cuts), int(halo)
         self.rank, self.world = comm.rank, comm.world
         self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
@@ -280,6 +306,8 @@ class TiledDFSPH:
         self.num_density_iters, self.num_divergence_iters = 1, 0  # dfsph.rs:51,55
         self.cap = cap_records
         self.exchanges = 0
+        self.rebalance_every, self.rebalances, self._steps = int(rebalance_every), 0, 0
+        self.boundary_margin = 256  # extra cells of boundary particles kept on either side (cuts may drift that far before a re-clip)
         self._valid = self._kvalid = float("inf")
 
     # ---- setup ------------------------------------------------------------------------------------------------------------
@@ -303,14 +331,46 @@ class TiledDFSPH:
             self.cap = max(1024, int(near * 1.5) + 1024)
         self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
         self.b.reserve(int(n_own * 1.25) + 4 * self.cap + 4096)
+        self.columns = len(pos) / max(1, int(c.max()) - int(c.min()) + 1) if len(pos) else 1.0
+        self.n_owned_local = n_own
+        self.boundary = None
         if boundary is not None and len(boundary):
-            bc = cell_coord(np.asarray(boundary, np.float32).reshape(-1, 2), self.axis, self.grid_min, h=self.h)
-            keep = (bc + (self.halo + 2) >= self.lo) & (bc < self.hi + self.halo + 2)
-            self.b.set_boundary(np.asarray(boundary, np.float32).reshape(-1, 2)[keep])
+            self.boundary = np.ascontiguousarray(boundary, np.float32).reshape(-1, 2)
+            self.boundary_cells = cell_coord(self.boundary, self.axis, self.grid_min, h=self.h)
+            self._clip_boundary()
         self.b.upload(pos[mine], vel[mine], ids[mine])
         self.bufs = self.b.make_buffers(self.cap)
         self.n_owned_global = len(pos)
         self.refresh()  # initial ghosts + the warm-up block (dfsph.rs:419-428): re-grid, densities, alpha
+
+    def _clip_boundary(self):
+        m = self.halo + 2 + (self.boundary_margin if self.rebalance_every else 0)
+        self._clip_lo, self._clip_hi = self.lo, self.hi
+        keep = (self.boundary_cells + m >= self.lo) & (self.boundary_cells < self.hi + m)
+        self.b.set_boundary(self.boundary[keep])
+
+    # ---- load balance -------------------------------------------------------------------------------------------------------
+    def _allgather(self, x):
+        out = []
+        for base in range(0, self.world, 8):  # the shared-memory reduction carries 8 doubles per call
+            m = min(8, self.world - base)
+            out += self.comm.allreduce_sum([float(x) if base + k == self.rank else 0.0 for k in range(m)])
+        return out
+
+    def rebalance(self):
+        """Move the cuts towards equal owned counts; takes effect in the refresh() that follows (the pack/drop/apply rules are
+        purely geometric, so particles of the band that changes owner travel as ordinary migrants)."""
+        counts = self._allgather(self.n_owned_local)
+        new = rebalance_cuts(self.cuts, counts, self.halo, self.columns, max_shift=max(1, self.halo // 4))
+        if new == self.cuts:
+            return False
+        self.cuts = new
+        self.lo, self.hi = new[self.rank], new[self.rank + 1]
+        self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
+        if self.boundary is not None and max(abs(self.lo - self._clip_lo), abs(self.hi - self._clip_hi)) > self.boundary_margin // 2:
+            self._clip_boundary()
+        self.rebalances += 1
+        return True
 
     # ---- halo ---------------------------------------------------------------------------------------------------------------
     def refresh(self):
@@ -349,6 +409,7 @@ class TiledDFSPH:
             self._need(min(self._valid - 2, self._avalid - 1))
             kvalid = min(self._valid - 1, self._avalid)
             s, n_owned = self.b.iteration(divergence, dt, iters == 0)
+            self.n_owned_local = int(n_owned)
             self._valid = min(self._valid - 2, self._avalid - 1)
             self._kvalid = kvalid
             iters += 1
@@ -388,6 +449,9 @@ class TiledDFSPH:
         self._valid = min(self._avalid, self._valid) - 1
         Id, avg_d, wd = self._loop(False, dt)                               # dfsph.rs:496
         self.b.advect(dt)                                                   # dfsph.rs:499-510 (ghosts move with their exact copies' v*)
+        self._steps += 1
+        if self.rebalance_every and self.world > 1 and self._steps % self.rebalance_every == 0:
+            self.rebalance()
         self.refresh()                                                      # migration + ghosts, dfsph.rs:512-518
         Iv, avg_v, wv = self._loop(True, dt)                                # dfsph.rs:521
         return dict(density_iterations=Id, divergence_iterations=Iv, warmstart_density=wd, warmstart_divergence=wv, avg_density_error=avg_d,
