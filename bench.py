@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
+    ap.add_argument("--rebalance-every", type=int, default=16, help="steps between re-partitions of the tile cuts (0 = never)")
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
@@ -130,7 +131,8 @@ def main():
             from yasph2d_amd.tiles import ThreadComm
 
             comm = ThreadComm(ThreadComm.Shared(1), 0)
-        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, axis, cuts, halo=args.halo)
+        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, axis, cuts, halo=args.halo,
+                           rebalance_every=args.rebalance_every)
         tiled.setup(pos, None, None, boundary)
         n = n_global // world
 
@@ -218,7 +220,8 @@ def main():
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
                 f"{world} spatial strips along {'xy'[tiled.axis]} cut at particle-count quantiles, {args.halo}-cell ghost halo, per step: 1 halo "
-                f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges in total",
+                f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
+                f"{tiled.rebalances} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
             },
             "step_model": {"bytes_per_particle_step": bstep,

@@ -370,8 +370,12 @@ struct GatherArgs {
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
 // n = number of sorted slots; n_in = size of the unsorted input (larger than n when the tile path dropped particles).
+// n_dev (tile path): the number of slots that really received a cell, still on the device when this kernel is launched over
+// the upper bound n.
 __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cidx, uint32_t n,
-                                                      uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a) {
+                                                      uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a,
+                                                      const uint32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t i = order[p];
@@ -447,41 +451,116 @@ struct HaloRec {
     float kappa, stiff;
     uint32_t pad;
 };
-// send-set flags: owned particles within `halo` cells of the left / right cut (particles that migrated across it included)
-__global__ __launch_bounds__(256) void k_tile_flags(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
-                                                     uint32_t halo, uint32_t* __restrict__ flag_l, uint32_t* __restrict__ flag_r) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 pv = PV[i];
-    const bool owned = (pid[i] >> 31) != 0 && pv.x == pv.x;
+// ---- halo pack: 3 launches -------------------------------------------------------------------------------------------------
+// Send sets: owned particles within `halo` cells of the left / right cut (particles that migrated across it included), in
+// ascending local index — the receiver's stable sort turns arrival order into the order inside a cell, so it must be
+// deterministic.  k_tile_count: per-workgroup counts; k_tile_offsets: one workgroup scans them and writes both headers;
+// k_tile_pack: recomputes the flags, ranks inside the workgroup with ballots, writes the records — and retires what this
+// tile no longer owns.
+__device__ __forceinline__ void tile_send_flags(const Consts& K, uint32_t halo, float4 pv, uint32_t id, bool has_l, bool has_r, bool& fl, bool& fr) {
+    const bool owned = (id >> 31) != 0 && pv.x == pv.x;
     const uint32_t c = tile_coord(K, pv.x, pv.y);
-    flag_l[i] = (owned && c < K.tile_lo + halo) ? 1u : 0u;
-    flag_r[i] = (owned && c + halo >= K.tile_hi) ? 1u : 0u;
+    fl = has_l && owned && c < K.tile_lo + halo;
+    fr = has_r && owned && c + halo >= K.tile_hi;
 }
-__global__ __launch_bounds__(256) void k_tile_pack(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, const float* __restrict__ kappa,
-                                                    const float* __restrict__ stiff, const uint2* __restrict__ scan, uint32_t n,
-                                                    HaloRec* __restrict__ out, uint32_t cap) {
+__global__ __launch_bounds__(256) void k_tile_count(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
+                                                     uint32_t halo, uint32_t has_l, uint32_t has_r, uint2* __restrict__ blk) {
+    __shared__ uint32_t wl[4], wr[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint2 se = scan[i];
-    if (se.y == se.x || se.x >= cap) return;
-    HaloRec r;
-    r.pv = PV[i];
-    r.id = pid[i] & 0x7FFFFFFFu;
-    r.kappa = kappa[i];
-    r.stiff = stiff[i];
-    r.pad = 0;
-    out[1 + se.x] = r;  // record 0 is the header (count)
+    bool fl = false, fr = false;
+    if (i < n) tile_send_flags(K, halo, PV[i], pid[i], has_l != 0, has_r != 0, fl, fr);
+    const uint32_t cl = (uint32_t)__popcll(__ballot(fl)), cr = (uint32_t)__popcll(__ballot(fr));
+    if ((threadIdx.x & 63) == 0) {
+        wl[threadIdx.x >> 6] = cl;
+        wr[threadIdx.x >> 6] = cr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(wl[0] + wl[1] + wl[2] + wl[3], wr[0] + wr[1] + wr[2] + wr[3]);
 }
-// Ghosts of the previous step vanish at the next re-grid (a NaN position gets no cell); so do owned particles that left the
-// tile AND its ghost band.  An owned particle that crossed a cut but is still inside the ghost band stays as a ghost: the new
-// owner receives the very same record in this exchange but cannot send it back before the next one.
-__global__ __launch_bounds__(256) void k_tile_drop(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid, uint32_t n,
-                                                    Consts K, uint32_t halo) {
+// exclusive scan of the per-workgroup counts in place (one workgroup of 1024); totals -> record 0 of each send buffer
+__global__ __launch_bounds__(1024) void k_tile_offsets(uint2* __restrict__ blk, uint32_t nb, HaloRec* __restrict__ out_l, HaloRec* __restrict__ out_r) {
+    __shared__ uint2 part[1024];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
+    uint2 acc = make_uint2(0, 0);
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint2 v = blk[b];
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint2 v = make_uint2(0, 0);
+        if (threadIdx.x >= off) v = part[threadIdx.x - off];
+        __syncthreads();
+        part[threadIdx.x].x += v.x;
+        part[threadIdx.x].y += v.y;
+        __syncthreads();
+    }
+    uint2 run = threadIdx.x ? part[threadIdx.x - 1] : make_uint2(0, 0);
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint2 v = blk[b];
+        blk[b] = run;
+        run.x += v.x;
+        run.y += v.y;
+    }
+    if (threadIdx.x == 1023) {
+        HaloRec h;
+        h.pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        h.kappa = h.stiff = 0.0f;
+        h.pad = 0;
+        h.id = part[1023].x;
+        out_l[0] = h;
+        h.id = part[1023].y;
+        out_r[0] = h;
+    }
+}
+// Records out; then: ghosts of the previous step vanish at the next re-grid (a NaN position gets no cell), and so do owned
+// particles that left the tile AND its ghost band.  An owned particle that crossed a cut but is still inside the ghost band
+// stays as a ghost: the new owner receives the very same record in this exchange but cannot send it back before the next one.
+__global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
+                                                    const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
+                                                    uint32_t halo, uint32_t has_l, uint32_t has_r, const uint2* __restrict__ blk,
+                                                    HaloRec* __restrict__ out_l, HaloRec* __restrict__ out_r, uint32_t cap) {
+    __shared__ uint32_t wl[4], wr[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool fl = false, fr = false;
+    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t id = 0;
+    if (i < n) {
+        pv = PV[i];
+        id = pid[i];
+        tile_send_flags(K, halo, pv, id, has_l != 0, has_r != 0, fl, fr);
+    }
+    const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+    if (lane == 0) {
+        wl[w] = (uint32_t)__popcll(ml);
+        wr[w] = (uint32_t)__popcll(mr);
+    }
+    __syncthreads();
     if (i >= n) return;
-    const float4 pv = PV[i];
-    const uint32_t id = pid[i];
+    if (fl || fr) {
+        const uint2 base = blk[blockIdx.x];
+        const unsigned long long below = (1ull << lane) - 1ull;
+        HaloRec r;
+        r.pv = pv;
+        r.id = id & 0x7FFFFFFFu;
+        r.kappa = kappa[i];
+        r.stiff = stiff[i];
+        r.pad = 0;
+        if (fl) {
+            uint32_t k = base.x + (uint32_t)__popcll(ml & below);
+            for (uint32_t q = 0; q < w; ++q) k += wl[q];
+            if (k < cap) out_l[1 + k] = r;  // record 0 is the header (count)
+        }
+        if (fr) {
+            uint32_t k = base.y + (uint32_t)__popcll(mr & below);
+            for (uint32_t q = 0; q < w; ++q) k += wr[q];
+            if (k < cap) out_r[1 + k] = r;
+        }
+    }
     const bool valid = (id >> 31) != 0 && pv.x == pv.x;
     const uint32_t c = tile_coord(K, pv.x, pv.y);
     const bool own = c >= K.tile_lo && c < K.tile_hi;
@@ -599,7 +678,9 @@ template <bool FUSE>
 __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
                                                          float* __restrict__ density, float* __restrict__ alpha,
-                                                         DevScalars* __restrict__ scal) {
+                                                         DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
+    if (blockIdx.x * 256 >= n) return;
     __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
     __shared__ float2 win[256 + 2 * WIN_HALO];  // positions of the sorted particles around this workgroup's 256
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
