@@ -23,8 +23,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv):
-    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step."""
+def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False):
+    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the 16-bit list format
+    of this build — every list-consuming traversal moves 2*kbar + 12 (entries, count word, base pair) instead of 4*kbar + 8."""
+    if compressed:
+        return 252 + 16 + 8 * kbar + Id * (84 + 8 + 4 * kbar) + Iv * (80 + 8 + 4 * kbar) + (Wd + Wv) * (44 + 4 + 2 * kbar)
     return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar)
 
 
@@ -68,6 +71,7 @@ def main():
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
+    ap.add_argument("--lists-32bit", action="store_true", help="disable the 16-bit neighbour-list compression (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -102,7 +106,10 @@ def main():
     n_global = len(pos)
     diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
     timer = y.TimeManager()
-    ctx = y.SphxContext(y.default_params(device=dev_index))
+    params = y.default_params(device=dev_index)
+    if args.lists_32bit:
+        params.list_span_limit = y.LISTS_32BIT
+    ctx = y.SphxContext(params)
 
     if world == 1 and not args.force_tiles:
         ctx.set_boundary(boundary)
@@ -199,7 +206,9 @@ def main():
 
     if rank == 0:
         value = n_global * args.steps / elapsed
-        bstep = bytes_per_particle_step(kbar if kbar is not None else 8.0, Id, Iv, Wd, Wv)  # tiles do not report k; 8.0 = lattice value
+        kb = kbar if kbar is not None else 8.0  # tiles do not report k; 8.0 = lattice value
+        bstep_ref = bytes_per_particle_step(kb, Id, Iv, Wd, Wv)
+        bstep = bytes_per_particle_step(kb, Id, Iv, Wd, Wv, compressed=not args.lists_32bit)
         out = {
             "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break",
             "value": value,
@@ -224,7 +233,8 @@ def main():
                 f"{tiled.rebalances} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
             },
-            "step_model": {"bytes_per_particle_step": bstep,
+            "step_model": {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
+                           "list_format": "32-bit" if args.lists_32bit else "16-bit offsets (32-bit fallback per wave)",
                            "achieved_GBs_whole_step_per_gpu": bstep * n * args.steps / elapsed / 1e9,
                            "frac_of_hbm_peak_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
         }

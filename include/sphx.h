@@ -70,8 +70,13 @@ typedef struct sphx_params {
     uint32_t fixed_density_iterations; /* 0 = adaptive (reference behaviour); >0 = run exactly this many (parity/bench mode) */
     uint32_t fixed_divergence_iterations;
     int32_t device;                    /* HIP device ordinal */
-    uint32_t reserved[4];
+    uint32_t list_span_limit;          /* neighbour-list compression (neighborhood_search.rs:262-273, README.md:12 "WIP"): a wave of 64
+                                          particles whose 3x3-cell candidates all lie within this many sorted slots stores 16-bit offsets
+                                          instead of 32-bit indices.  0 = default (65536); SPHX_LISTS_32BIT = never compress; smaller
+                                          values only make more waves fall back to 32 bit (test aid).  Results never depend on it. */
+    uint32_t reserved[3];
 } sphx_params;
+#define SPHX_LISTS_32BIT 0xFFFFFFFFu
 
 /* Per-step report (the reference only println!s these; dfsph.rs:227-243,382-398). */
 typedef struct sphx_step_stats {

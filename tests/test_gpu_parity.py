@@ -15,8 +15,9 @@ from oracle.oracle import KERNEL_POLY6, KERNEL_SPIKY, KERNEL_WENDLAND, Oracle
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(pos, boundary=None, search_radius=None, fixed=(0, 0)):
+def make_pair(pos, boundary=None, search_radius=None, fixed=(0, 0), list_span_limit=0):
     p = y.default_params(fixed_iterations=fixed)
+    p.list_span_limit = list_span_limit
     if search_radius is not None:
         # NeighborhoodSearch::new(radius) of the criterion bench: radius = cell size = smoothing length
         p.smoothing_length = search_radius
@@ -127,6 +128,21 @@ def test_dfsph_dam_break_fixed_iterations():
     pos, boundary = dam_break(1.0)
     ctx, o = make_pair(pos, boundary, fixed=(3, 2))
     run_steps(ctx, o, 60, check_every=10)
+
+
+@pytest.mark.parametrize("span", [y.LISTS_32BIT, 150, 1000])
+def test_list_formats_do_not_change_results(span):
+    """Neighbour-list compression: all waves 32-bit / a mix of 16- and 32-bit waves (a 3x3 box spans a few hundred sorted slots
+    at this size, so limits of 150 and 1000 put many or a few waves on the 32-bit fallback).  Lists, states and scalars stay
+    bit-identical to the oracle, through free fall and the impact (static neighbours, > 16 neighbours per particle)."""
+    pos, boundary = dam_break(float(np.sqrt(20000 / 4050)))
+    ctx, o = make_pair(pos, boundary, list_span_limit=span)
+    ctx.update_neighborhood()
+    o.update_neighborhood()
+    compare_grid(ctx, o)
+    pos, boundary = dam_break(1.0)
+    ctx, o = make_pair(pos, boundary, list_span_limit=span)
+    run_steps(ctx, o, 330, check_every=55)
 
 
 def test_dfsph_scale_40k():

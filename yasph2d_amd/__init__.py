@@ -22,6 +22,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+LISTS_32BIT = 0xFFFFFFFF  # sphx_params.list_span_limit: never compress the neighbour lists
+
+
 def default_params(smoothing_factor=2.0, particle_density=10000.0, fluid_density=100.0, device=0, fixed_iterations=(0, 0)):
     """sphx_default_params: the constants of the reference app (main.rs:85-89, dfsph.rs:49-55)."""
     p = SphxParams()

@@ -29,7 +29,8 @@ class SphxParams(C.Structure):
         ("fixed_density_iterations", C.c_uint32),
         ("fixed_divergence_iterations", C.c_uint32),
         ("device", C.c_int32),
-        ("reserved", C.c_uint32 * 4),
+        ("list_span_limit", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 

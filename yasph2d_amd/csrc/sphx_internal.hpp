@@ -40,6 +40,16 @@ struct Consts {
     // spatial tile owned by this context (multi-GPU): cells with tile_lo <= c < tile_hi along tile_axis; reductions only count
     // owned particles.  Single-GPU default: [0, 65536).
     uint32_t tile_axis, tile_lo, tile_hi;
+    // a wave whose lanes' candidate index spans all stay <= span_limit stores 16-bit list entries (65536; 0 forces 32-bit lists)
+    uint32_t span_limit;
+};
+
+// wave-sliced ELL neighbour lists: entry k of particle i; counts[i] = format<<31 | count_total<<16 | count_dynamic;
+// bases[i] = {first dynamic candidate slot, soff + first static candidate slot} (16-bit format only)
+struct NbView {
+    const uint32_t* list;
+    const uint32_t* counts;
+    const uint2* bases;
 };
 
 // Two-level Morton cell grid.  dir[] is a small host-built 2D directory over the 64x64-cell blocks of the
@@ -142,7 +152,9 @@ struct sphx_ctx {
     std::vector<float> h_boundary;  // host copy of the boundary (caller order): the static directory is built on the host
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
-    uint32_t* nb_counts = nullptr;  // (count_total << 16) | count_dynamic
+    uint32_t* nb_counts = nullptr;  // format << 31 | count_total << 16 | count_dynamic
+    uint2* nb_bases = nullptr;
+    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_bases}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;

@@ -677,7 +677,7 @@ __device__ __forceinline__ void lookup9(const GridView& g, const uint32_t (&c)[9
 template <bool FUSE>
 __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
-                                                         float* __restrict__ density, float* __restrict__ alpha,
+                                                         uint2* __restrict__ bases, float* __restrict__ density, float* __restrict__ alpha,
                                                          DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (blockIdx.x * 256 >= n) return;
@@ -693,6 +693,8 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
     for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
     __syncthreads();
     uint32_t cd = 0, ct = 0;
+    uint32_t wide = 0, lo_d = 0xFFFFFFFFu, lo_s = 0xFFFFFFFFu;  // list format of this wave (see NbHead), bases of the 16-bit offsets
+    uint16_t* const lp16 = (uint16_t*)(list + (size_t)(i >> 6) * 4096) + lane;
     float2 pi = make_float2(0.0f, 0.0f);
     if (i < n) {
         pi = lds_read_f2(&win[i - w0]);
@@ -720,6 +722,7 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
         uint32_t s[9], e[9];
         lookup9(gd, c, s, e);
+        uint32_t far = 0;  // OR of all (entry - base) offsets: decides the list format of rows 0..STAGE_ROWS-1 at flush time
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // software pipeline: the next candidate's ds_read is in flight while the current one is tested
@@ -736,6 +739,8 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                         mytile[ct * 64] = j;
                     else
                         list[ell_index(i, ct)] = j;
+                    lo_d = min(lo_d, j);  // ascending: the first accepted entry
+                    far |= j - lo_d;
                     ct += 1;
                 }
             }
@@ -764,6 +769,8 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                             mytile[ct * 64] = j;
                         else
                             list[ell_index(i, ct)] = j;
+                        lo_s = min(lo_s, j);
+                        far |= j - lo_s;
                         ct += 1;
                     }
                 }
@@ -771,15 +778,22 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         }
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
-        counts[i] = (ct << 16) | cd;
+        wide = __any(far >= K.span_limit) ? 1u : 0u;
+        counts[i] = (wide << 31) | (ct << 16) | cd;
+        bases[i] = make_uint2(lo_d, soff + lo_s);
         if (flags) atomicOr(&scal->flags, flags);
     }
-    // staged rows -> global, one coalesced 256-byte row per store (lanes past their own count write don't-care values)
+    // staged rows -> global, one coalesced row per store (lanes past their own count write don't-care values)
     uint32_t m = min(ct, STAGE_ROWS);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    const size_t row0 = (size_t)(i >> 6) * 64;
-    for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = tile[w][k][lane];
+    wide = __builtin_amdgcn_readfirstlane(wide);  // lane 0 took part above whenever any lane of the wave did
+    if (wide) {
+        const size_t row0 = (size_t)(i >> 6) * 64;
+        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = tile[w][k][lane];
+    } else {
+        for (uint32_t k = 0; k < m; ++k) lp16[k * 64] = (uint16_t)(tile[w][k][lane] - (k < cd ? lo_d : lo_s));
+    }
 
     if (FUSE && i < n) {
         // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order
@@ -830,18 +844,61 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 #define NB_BATCH 4
 
+// Compressed lists (neighborhood_search.rs:262-273 sketches the idea; README.md:12 calls it WIP).  The entries of one particle
+// are ascending sorted-array indices out of its 3x3 cell box, so they sit within a short span above the first candidate: a
+// wave whose 64 particles all span < 65536 slots stores rows 0..STAGE_ROWS-1 (the rows staged in LDS by the build) as 16-bit
+// offsets from a per-particle base (128-byte rows instead of 256), any other wave keeps 32-bit rows; rows >= STAGE_ROWS are
+// always 32-bit (they lie behind the 16-bit rows of the slice).  The format bit is wave-uniform (bit 31 of every lane's count word).
+struct NbHead {
+    uint32_t cd, ct, base_d, base_s, soff;
+    bool wide;
+    const uint32_t* lp;
+    const uint16_t* lp16;
+};
+__device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t soff) {
+    NbHead h;
+    const uint32_t c = nb.counts[i];
+    h.cd = c & 0xffffu;
+    h.ct = (c >> 16) & 0x7fffu;
+    h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
+    h.lp = nb.list + ell_index(i, 0);
+    h.lp16 = (const uint16_t*)(nb.list + (size_t)(i >> 6) * 4096) + (i & 63u);
+    h.soff = soff;
+    h.base_d = 0;
+    h.base_s = soff;
+    if (!h.wide) {
+        const uint2 b = nb.bases[i];
+        h.base_d = b.x;
+        h.base_s = b.y;
+    }
+    return h;
+}
+// record indices ([N|B] slot) of entries k0 .. k0+NB_BATCH-1; entries >= lim give `self` (a harmless gather)
+__device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t lim, uint32_t self, uint32_t (&j)[NB_BATCH]) {
+    static_assert(STAGE_ROWS % NB_BATCH == 0, "a batch never straddles the 16-bit / 32-bit rows");
+    const bool w32 = h.wide || k0 >= STAGE_ROWS;
+    if (w32) {
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? h.lp[(size_t)(k0 + u) * 64] : 0u;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? (uint32_t)h.lp16[(size_t)(k0 + u) * 64] : 0u;
+    }
+    const uint32_t bd = w32 ? 0u : h.base_d, bs = w32 ? h.soff : h.base_s;
+#pragma unroll
+    for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? j[u] + ((k0 + u < h.cd) ? bd : bs) : self;
+}
+
 // a8 / a9 stand-alone (the pieces benches/ and the warm-up drive): densities and alpha factors from a finished list
 // KIND: 0 Wendland, 1 Poly6, 2 Spiky
 template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
-                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
-                                                        float* __restrict__ density, float* __restrict__ alpha) {
+                                                        NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float2 ri = posA[i];
-    const uint32_t c = counts[i];
-    const uint32_t cd = c & 0xffffu, ct = c >> 16;
-    const uint32_t* lp = list + ell_index(i, 0);
+    const NbHead h = nb_head(nb, i, soff);
+    const uint32_t ct = h.ct;
     float rho = 0.0f;
     if (DENSITY) {
         if (KIND == 0) rho = wendland_eval(K, 0.0f) * K.mass;
@@ -852,10 +909,9 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
         uint32_t j[NB_BATCH];
         float2 rj[NB_BATCH];
+        nb_fetch(h, k0, ct, i, j);
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) rj[u] = posA[(k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u]];
+        for (int u = 0; u < NB_BATCH; ++u) rj[u] = posA[j[u]];
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) {
             if (k0 + u < ct) {
@@ -889,23 +945,21 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
-                                                      float dt, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
-                                                      float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
+                                                      float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
                                                       Mailbox* __restrict__ mb, uint32_t seq) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float vsq = 0.0f;
     if (i < n) {
         const float4 pvi = PV[i];
-        const uint32_t cd = counts[i] & 0xffffu;
-        const uint32_t* lp = list + ell_index(i, 0);
+        const NbHead h = nb_head(nb, i, 0u);
+        const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
         for (uint32_t k0 = 0; k0 < cd; k0 += NB_BATCH) {
             uint32_t j[NB_BATCH];
             float4 r[NB_BATCH];
             float rho[NB_BATCH];
-#pragma unroll
-            for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < cd) ? lp[(size_t)(k0 + u) * 64] : i;
+            nb_fetch(h, k0, cd, i, j);
 #pragma unroll
             for (int u = 0; u < NB_BATCH; ++u) {
                 r[u] = PV[j[u]];
@@ -963,26 +1017,23 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
 template <bool DIVERGENCE>
 __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
-                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
-                                                        float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
+                                                        NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
                                                         DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
-        const uint32_t c = counts[i];
-        const uint32_t cd = c & 0xffffu, ct = c >> 16;
+        const NbHead h = nb_head(nb, i, soff);
+        const uint32_t ct = h.ct;
         const float4 pvi = PV[i];
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
-            const uint32_t* lp = list + ell_index(i, 0);
             float delta = 0.0f;
             for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
                 uint32_t j[NB_BATCH];
                 float4 r[NB_BATCH];
+                nb_fetch(h, k0, ct, i, j);
 #pragma unroll
-                for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
-#pragma unroll
-                for (int u = 0; u < NB_BATCH; ++u) r[u] = PV[(k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u]];
+                for (int u = 0; u < NB_BATCH; ++u) r[u] = PV[j[u]];
 #pragma unroll
                 for (int u = 0; u < NB_BATCH; ++u) {
                     if (k0 + u < ct) {
@@ -1031,12 +1082,11 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
 // WARM=false: k comes from PK (own and neighbours'), warm[i] += k_i.   WARM=true: k = 0.5*max(warm, lim) (clamp applied on read).
 template <bool WARM, bool INV_DT>
 __global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
-                                                  uint32_t soff, Consts K, float inv_dt, float lim, const uint32_t* __restrict__ list,
-                                                  const uint32_t* __restrict__ counts) {
+                                                  uint32_t soff, Consts K, float inv_dt, float lim, NbView nb) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = counts[i];
-    const uint32_t cd = c & 0xffffu, ct = c >> 16;
+    const NbHead h = nb_head(nb, i, soff);
+    const uint32_t cd = h.cd, ct = h.ct;
     const float4 pvi = PV[i];
     float ki;
     float2 ri;
@@ -1048,17 +1098,15 @@ __global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const 
         ki = pki.z;
         ri = make_float2(pki.x, pki.y);
     }
-    const uint32_t* lp = list + ell_index(i, 0);
     float dx = 0.0f, dy = 0.0f;
     for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
         uint32_t j[NB_BATCH];
         float4 r[NB_BATCH];
         float wj[NB_BATCH];
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < ct) ? lp[(size_t)(k0 + u) * 64] : i;
+        nb_fetch(h, k0, ct, i, j);
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) {
-            const uint32_t idx = (k0 + u < ct && k0 + u >= cd) ? j[u] + soff : j[u];
+            const uint32_t idx = j[u];
             if (WARM) {
                 r[u] = PV[idx];
                 wj[u] = (k0 + u < cd) ? warm[j[u]] : 0.0f;
@@ -1101,16 +1149,21 @@ __global__ __launch_bounds__(256) void k_export_counts(const uint32_t* __restric
     if (i >= n) return;
     const uint32_t c = counts[i];
     out[2 * i] = (uint16_t)(c & 0xffffu);
-    out[2 * i + 1] = (uint16_t)(c >> 16);
-    totals[i] = c >> 16;
+    out[2 * i + 1] = (uint16_t)((c >> 16) & 0x7fffu);
+    totals[i] = (c >> 16) & 0x7fffu;
 }
-__global__ __launch_bounds__(256) void k_export_lists(const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts,
-                                                       const uint32_t* __restrict__ start, uint32_t n, uint32_t* __restrict__ out) {
+// the reference's list content: sorted fluid index for dynamic entries, boundary index for static ones
+__global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, const uint32_t* __restrict__ start, uint32_t n,
+                                                       uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t ct = counts[i] >> 16;
+    const NbHead h = nb_head(nb, i, soff);
     const uint32_t s = start[i];
-    for (uint32_t k = 0; k < ct; ++k) out[s + k] = list[ell_index(i, k)];
+    for (uint32_t k = 0; k < h.ct; ++k) {
+        const bool w32 = h.wide || k >= STAGE_ROWS;
+        const uint32_t raw = w32 ? h.lp[(size_t)k * 64] : (uint32_t)h.lp16[(size_t)k * 64];
+        out[s + k] = raw + (w32 ? 0u : (k < h.cd ? h.base_d : h.base_s - soff));
+    }
 }
 __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos, uint32_t n, Consts K, uint32_t* __restrict__ key) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
