@@ -97,6 +97,13 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
 
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
+// Gather base[idx] with a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address
+// arithmetic per access (scalar base + 32-bit vector offset addressing).  Arrays gathered this way stay below 4 GiB:
+// alloc_particles refuses capN + capB >= 2^28.
+template <class T>
+__device__ __forceinline__ T gat(const T* __restrict__ base, uint32_t idx) {
+    return *(const T*)((const char*)base + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // device-wide exclusive scan (reduce / scan-partials / apply), length may live on the device
@@ -660,12 +667,12 @@ __device__ __forceinline__ void lookup9(const GridView& g, const uint32_t (&c)[9
         const uint32_t blk = c[t] >> (2 * BLOCK_SHIFT);
         if (blk != pblk) {
             const uint32_t bx = compact1by1(blk) - g.bx0, by = compact1by1(blk >> 1) - g.by0;
-            poff = (bx < g.nbx && by < g.nby) ? g.dir[by * g.nbx + bx] : EMPTY;
+            poff = (bx < g.nbx && by < g.nby) ? gat(g.dir, by * g.nbx + bx) : EMPTY;
             pblk = blk;
         }
         uint32_t a = 0, b = 0;
         if (poff != EMPTY && c[t] != 0xFFFFFFFFu) {
-            const uint2 se = g.fine[poff + (c[t] & (BLOCK_CELLS - 1u))];
+            const uint2 se = gat(g.fine, poff + (c[t] & (BLOCK_CELLS - 1u)));
             a = se.x;
             b = se.y;
         }
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                 const uint32_t wj = j - w0;
                 float2 pj = pn;  // always from LDS; the rare out-of-window candidate re-reads from global
                 pn = lds_read_f2(&win[min(wj + 1u, wlen - 1u)]);
-                if (wj >= wlen) pj = posA[j];
+                if (wj >= wlen) pj = gat(posA, j);
                 const float dx = pj.x - pi.x, dy = pj.y - pi.y;
                 const float d2 = dx * dx + dy * dy;
                 if (d2 <= K.radius_sq && d2 > 1.0e-10f && ct < MAX_NEIGHBORS) {
@@ -752,14 +759,14 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         for (int q = 0; q < 4; ++q) {
             const uint32_t bx = ((cx + ((q & 1) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.bx0;
             const uint32_t by = ((cy + ((q & 2) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.by0;
-            if (bx < gs.nbx && by < gs.nby) near_static |= gs.dir[by * gs.nbx + bx] != EMPTY;
+            if (bx < gs.nbx && by < gs.nby) near_static |= gat(gs.dir, by * gs.nbx + bx) != EMPTY;
         }
         if (__any(near_static)) {
         lookup9(gs, c, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             for (uint32_t j = s[t]; j < e[t]; ++j) {
-                const float2 pj = posA[soff + j];
+                const float2 pj = gat(posA, soff + j);
                 const float dx = pj.x - pi.x, dy = pj.y - pi.y;
                 const float d2 = dx * dx + dy * dy;
                 if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
@@ -806,9 +813,9 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
             if (k < cd) {
                 const uint32_t wj = j - w0;
                 rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
-                if (wj >= wlen) rj = posA[j];
+                if (wj >= wlen) rj = gat(posA, j);
             } else {
-                rj = posA[soff + j];
+                rj = gat(posA, soff + j);
             }
             const float dx = rj.x - pi.x, dy = rj.y - pi.y;
             const float r = sqrtf(dx * dx + dy * dy);
@@ -852,8 +859,8 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
 struct NbHead {
     uint32_t cd, ct, base_d, base_s, soff;
     bool wide;
-    const uint32_t* lp;
-    const uint16_t* lp16;
+    const char* rows;  // this wave's 16 KiB slice of the list buffer (wave-uniform: scalar base + 32-bit lane offsets)
+    uint32_t lane;
 };
 __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t soff) {
     NbHead h;
@@ -861,8 +868,8 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t
     h.cd = c & 0xffffu;
     h.ct = (c >> 16) & 0x7fffu;
     h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
-    h.lp = nb.list + ell_index(i, 0);
-    h.lp16 = (const uint16_t*)(nb.list + (size_t)(i >> 6) * 4096) + (i & 63u);
+    h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
+    h.lane = i & 63u;
     h.soff = soff;
     h.base_d = 0;
     h.base_s = soff;
@@ -873,20 +880,26 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t
     }
     return h;
 }
-// record indices ([N|B] slot) of entries k0 .. k0+NB_BATCH-1; entries >= lim give `self` (a harmless gather)
-__device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t lim, uint32_t self, uint32_t (&j)[NB_BATCH]) {
+// Record indices ([N|B] slot) of entries k0 .. k0+NB_BATCH-1 (k0 < lim).  Entries past the end repeat entry lim-1, so every
+// load of a batch is unconditional — no branch per entry, all gathers of a batch in flight together; the callers discard the
+// padded terms with a select.
+__device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t lim, uint32_t (&j)[NB_BATCH]) {
     static_assert(STAGE_ROWS % NB_BATCH == 0, "a batch never straddles the 16-bit / 32-bit rows");
     const bool w32 = h.wide || k0 >= STAGE_ROWS;
+    const uint32_t last = lim - 1u;
+    uint32_t kk[NB_BATCH];
+#pragma unroll
+    for (int u = 0; u < NB_BATCH; ++u) kk[u] = min(k0 + u, last);
     if (w32) {
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? h.lp[(size_t)(k0 + u) * 64] : 0u;
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = *(const uint32_t*)(h.rows + (uint32_t)((kk[u] * 64u + h.lane) * 4u));
     } else {
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? (uint32_t)h.lp16[(size_t)(k0 + u) * 64] : 0u;
+        for (int u = 0; u < NB_BATCH; ++u) j[u] = *(const uint16_t*)(h.rows + (uint32_t)((kk[u] * 64u + h.lane) * 2u));
     }
     const uint32_t bd = w32 ? 0u : h.base_d, bs = w32 ? h.soff : h.base_s;
 #pragma unroll
-    for (int u = 0; u < NB_BATCH; ++u) j[u] = (k0 + u < lim) ? j[u] + ((k0 + u < h.cd) ? bd : bs) : self;
+    for (int u = 0; u < NB_BATCH; ++u) j[u] += (kk[u] < h.cd) ? bd : bs;
 }
 
 // a8 / a9 stand-alone (the pieces benches/ and the warm-up drive): densities and alpha factors from a finished list
@@ -909,12 +922,13 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
         uint32_t j[NB_BATCH];
         float2 rj[NB_BATCH];
-        nb_fetch(h, k0, ct, i, j);
+        nb_fetch(h, k0, ct, j);
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) rj[u] = posA[j[u]];
+        for (int u = 0; u < NB_BATCH; ++u) rj[u] = gat(posA, j[u]);
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) {
-            if (k0 + u < ct) {
+            {
+                const bool live = k0 + u < ct;
                 const float dx = rj[u].x - ri.x, dy = rj[u].y - ri.y;
                 const float r_sq = dx * dx + dy * dy;
                 const float r = sqrtf(r_sq);
@@ -923,16 +937,18 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
                     if (KIND == 0) wv = wendland_eval(K, r);
                     if (KIND == 1) wv = poly6_eval(K, r_sq);
                     if (KIND == 2) wv = spiky_eval(K, r);
-                    rho += wv * K.mass;
+                    const float t = rho + wv * K.mass;
+                    rho = live ? t : rho;
                 }
                 if (ALPHA) {
                     const float q = fminf(r * K.w_hinv, 1.0f);
                     const float omq = 1.0f - q;
                     const float sg = K.w_ngrad * omq * omq * omq;
                     const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-                    gsx += gx;
-                    gsy += gy;
-                    gss += gx * gx + gy * gy;
+                    const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
+                    gsx = live ? tx : gsx;
+                    gsy = live ? ty : gsy;
+                    gss = live ? ts : gss;
                 }
             }
         }
@@ -959,21 +975,21 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
             uint32_t j[NB_BATCH];
             float4 r[NB_BATCH];
             float rho[NB_BATCH];
-            nb_fetch(h, k0, cd, i, j);
+            nb_fetch(h, k0, cd, j);
 #pragma unroll
             for (int u = 0; u < NB_BATCH; ++u) {
-                r[u] = PV[j[u]];
-                rho[u] = density[j[u]];
+                r[u] = gat(PV, j[u]);
+                rho[u] = gat(density, j[u]);
             }
 #pragma unroll
             for (int u = 0; u < NB_BATCH; ++u) {
-                if (k0 + u < cd) {
-                    const float dx = r[u].x - pvi.x, dy = r[u].y - pvi.y;
-                    const float r_sq = dx * dx + dy * dy;
-                    const float f = em * poly6_eval(K, r_sq) / (rho[u] * dt);
-                    ax += f * (r[u].z - pvi.z);
-                    ay += f * (r[u].w - pvi.w);
-                }
+                const bool live = k0 + u < cd;
+                const float dx = r[u].x - pvi.x, dy = r[u].y - pvi.y;
+                const float r_sq = dx * dx + dy * dy;
+                const float f = em * poly6_eval(K, r_sq) / (rho[u] * dt);
+                const float tx = ax + f * (r[u].z - pvi.z), ty = ay + f * (r[u].w - pvi.w);
+                ax = live ? tx : ax;
+                ay = live ? ty : ay;
             }
         }
         accel[i] = make_float2(ax, ay);
@@ -1031,17 +1047,16 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
             for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
                 uint32_t j[NB_BATCH];
                 float4 r[NB_BATCH];
-                nb_fetch(h, k0, ct, i, j);
+                nb_fetch(h, k0, ct, j);
 #pragma unroll
-                for (int u = 0; u < NB_BATCH; ++u) r[u] = PV[j[u]];
+                for (int u = 0; u < NB_BATCH; ++u) r[u] = gat(PV, j[u]);
 #pragma unroll
                 for (int u = 0; u < NB_BATCH; ++u) {
-                    if (k0 + u < ct) {
-                        const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
-                        // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
-                        const float dvx = pvi.z - r[u].z, dvy = pvi.w - r[u].w;
-                        delta += dvx * g.x + dvy * g.y;
-                    }
+                    const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+                    // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
+                    const float dvx = pvi.z - r[u].z, dvy = pvi.w - r[u].w;
+                    const float t = delta + (dvx * g.x + dvy * g.y);
+                    delta = (k0 + u < ct) ? t : delta;
                 }
             }
             if (DIVERGENCE) {
@@ -1103,29 +1118,26 @@ __global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const 
         uint32_t j[NB_BATCH];
         float4 r[NB_BATCH];
         float wj[NB_BATCH];
-        nb_fetch(h, k0, ct, i, j);
+        nb_fetch(h, k0, ct, j);
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) {
             const uint32_t idx = j[u];
             if (WARM) {
-                r[u] = PV[idx];
-                wj[u] = (k0 + u < cd) ? warm[j[u]] : 0.0f;
+                r[u] = gat((const float4*)PV, idx);
+                wj[u] = gat((const float*)warm, idx < soff ? idx : i);  // warm[] has no boundary tail; static entries do not use it
             } else {
-                r[u] = PK[idx];
+                r[u] = gat(PK, idx);
             }
         }
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) {
-            if (k0 + u < ct) {
-                const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
-                float s;
-                if (k0 + u < cd)
-                    s = ki + (WARM ? 0.5f * fmaxf(wj[u], lim) : r[u].z);  // (ki + kj), dfsph.rs:151 / :184 / :305 / :335
-                else
-                    s = ki;  // static neighbours, dfsph.rs:156 / :188 / :309 / :339
-                dx += s * g.x;
-                dy += s * g.y;
-            }
+            const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+            // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
+            const float kj = WARM ? 0.5f * fmaxf(wj[u], lim) : r[u].z;
+            const float s = (k0 + u < cd) ? ki + kj : ki;
+            const float tx = dx + s * g.x, ty = dy + s * g.y;
+            dx = (k0 + u < ct) ? tx : dx;
+            dy = (k0 + u < ct) ? ty : dy;
         }
     }
     float2 o;
@@ -1161,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
     const uint32_t s = start[i];
     for (uint32_t k = 0; k < h.ct; ++k) {
         const bool w32 = h.wide || k >= STAGE_ROWS;
-        const uint32_t raw = w32 ? h.lp[(size_t)k * 64] : (uint32_t)h.lp16[(size_t)k * 64];
+        const uint32_t raw = w32 ? *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u)) : *(const uint16_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 2u));
         out[s + k] = raw + (w32 ? 0u : (k < h.cd ? h.base_d : h.base_s - soff));
     }
 }
