@@ -97,6 +97,13 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
 
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
+// XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
+// with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
+// and below is fetched into ~3 different L2s.  Here XCD x owns the x-th contiguous eighth of the particles — a compact patch
+// of the domain — in EVERY per-particle kernel, so neighbour gathers (and the next kernel's reads of what this one wrote) stay
+// in one L2.  Grids of these kernels are multiples of 8 (nblocks()).  Placement is a speed hint only, never a correctness one.
+__device__ __forceinline__ uint32_t xcd_bid() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
 // Gather base[idx] with a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address
 // arithmetic per access (scalar base + 32-bit vector offset addressing).  Arrays gathered this way stay below 4 GiB:
 // alloc_particles refuses capN + capB >= 2^28.
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, floa
                                                     uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
                                                     uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
                                                     DevScalars* __restrict__ scal) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = EMPTY;
     if (i < n) {
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, floa
 // order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order)
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
                                                   const uint2* __restrict__ fine, uint32_t* __restrict__ order) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t sl = slot[i];
     if (sl == EMPTY) return;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
                                                       uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a,
                                                       const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t p = xcd_bid() * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t i = order[p];
     if (i >= n_in) return;
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(256) void k_unpack_vel(const float4* __restrict__ P
 // ---- multi-GPU tiles -------------------------------------------------------------------------------------------------
 // plain advect (dfsph.rs:499-510) for the tile path, where the halo exchange sits between the advection and the re-grid
 __global__ __launch_bounds__(256) void k_advect(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t n, float dt) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     float4 pv = PV[i];
     pv.x = pv.x + pv.z * dt;
@@ -687,14 +694,14 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                                                          uint2* __restrict__ bases, float* __restrict__ density, float* __restrict__ alpha,
                                                          DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
-    if (blockIdx.x * 256 >= n) return;
+    if (xcd_bid() * 256 >= n) return;
     __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
     __shared__ float2 win[256 + 2 * WIN_HALO];  // positions of the sorted particles around this workgroup's 256
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
     // hundred sorted slots, so the candidate scan below reads LDS instead of issuing ~40 scattered global loads per wave.
-    const uint32_t b0 = blockIdx.x * 256;
+    const uint32_t b0 = xcd_bid() * 256;
     const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
     const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
     for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
@@ -871,13 +878,9 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     h.lane = i & 63u;
     h.soff = soff;
-    h.base_d = 0;
-    h.base_s = soff;
-    if (!h.wide) {
-        const uint2 b = nb.bases[i];
-        h.base_d = b.x;
-        h.base_s = b.y;
-    }
+    const uint2 b = nb.bases[i];  // unconditional: issued together with the count word, not after it
+    h.base_d = h.wide ? 0u : b.x;
+    h.base_s = h.wide ? soff : b.y;
     return h;
 }
 // Record indices ([N|B] slot) of entries k0 .. k0+NB_BATCH-1 (k0 < lim).  Entries past the end repeat entry lim-1, so every
@@ -902,12 +905,31 @@ __device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t 
     for (int u = 0; u < NB_BATCH; ++u) j[u] += (kk[u] < h.cd) ? bd : bs;
 }
 
+// Software-pipelined traversal of entries 0..lim-1 in list order.  The kernels are bound by memory LATENCY (a wave spends ~70 %
+// of its life parked on s_waitcnt, profiles/), so the dependent chain index -> record is overlapped: the index loads of batch
+// b+1 are issued right after the record gathers of batch b, before those are consumed.
+//   gather(slot) -> record (any type);   consume(record, k) must ignore k >= lim (padded entries repeat entry lim-1).
+template <class G, class C>
+__device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, G&& gather, C&& consume) {
+    if (lim == 0) return;
+    uint32_t jn[NB_BATCH];
+    nb_fetch(h, 0, lim, jn);
+    for (uint32_t k0 = 0; k0 < lim; k0 += NB_BATCH) {
+        decltype(gather(0u)) r[NB_BATCH];
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) r[u] = gather(jn[u]);
+        nb_fetch(h, k0 + NB_BATCH, lim, jn);  // clamped to the last entry when the list ends here
+#pragma unroll
+        for (int u = 0; u < NB_BATCH; ++u) consume(r[u], k0 + (uint32_t)u);
+    }
+}
+
 // a8 / a9 stand-alone (the pieces benches/ and the warm-up drive): densities and alpha factors from a finished list
 // KIND: 0 Wendland, 1 Poly6, 2 Spiky
 template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     const float2 ri = posA[i];
     const NbHead h = nb_head(nb, i, soff);
@@ -919,40 +941,32 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
         if (KIND == 2) rho = spiky_eval(K, 0.0f) * K.mass;
     }
     float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-    for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
-        uint32_t j[NB_BATCH];
-        float2 rj[NB_BATCH];
-        nb_fetch(h, k0, ct, j);
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) rj[u] = gat(posA, j[u]);
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) {
-            {
-                const bool live = k0 + u < ct;
-                const float dx = rj[u].x - ri.x, dy = rj[u].y - ri.y;
-                const float r_sq = dx * dx + dy * dy;
-                const float r = sqrtf(r_sq);
-                if (DENSITY) {
-                    float wv;
-                    if (KIND == 0) wv = wendland_eval(K, r);
-                    if (KIND == 1) wv = poly6_eval(K, r_sq);
-                    if (KIND == 2) wv = spiky_eval(K, r);
-                    const float t = rho + wv * K.mass;
-                    rho = live ? t : rho;
-                }
-                if (ALPHA) {
-                    const float q = fminf(r * K.w_hinv, 1.0f);
-                    const float omq = 1.0f - q;
-                    const float sg = K.w_ngrad * omq * omq * omq;
-                    const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-                    const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
-                    gsx = live ? tx : gsx;
-                    gsy = live ? ty : gsy;
-                    gss = live ? ts : gss;
-                }
+    nb_traverse(
+        h, ct, [&](uint32_t slot) { return gat(posA, slot); },
+        [&](float2 rj, uint32_t k) {
+            const bool live = k < ct;
+            const float dx = rj.x - ri.x, dy = rj.y - ri.y;
+            const float r_sq = dx * dx + dy * dy;
+            const float r = sqrtf(r_sq);
+            if (DENSITY) {
+                float wv;
+                if (KIND == 0) wv = wendland_eval(K, r);
+                if (KIND == 1) wv = poly6_eval(K, r_sq);
+                if (KIND == 2) wv = spiky_eval(K, r);
+                const float t = rho + wv * K.mass;
+                rho = live ? t : rho;
             }
-        }
-    }
+            if (ALPHA) {
+                const float q = fminf(r * K.w_hinv, 1.0f);
+                const float omq = 1.0f - q;
+                const float sg = K.w_ngrad * omq * omq * omq;
+                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+                const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
+                gsx = live ? tx : gsx;
+                gsy = live ? ty : gsy;
+                gss = live ? ts : gss;
+            }
+        });
     if (DENSITY) density[i] = fmaxf(rho, K.rho0);                                  // fluidparticleworld.rs:229
     if (ALPHA) alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);     // dfsph.rs:94
 }
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
 __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
                                                       Mailbox* __restrict__ mb, uint32_t seq) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     float vsq = 0.0f;
     if (i < n) {
         const float4 pvi = PV[i];
@@ -971,27 +985,20 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
-        for (uint32_t k0 = 0; k0 < cd; k0 += NB_BATCH) {
-            uint32_t j[NB_BATCH];
-            float4 r[NB_BATCH];
-            float rho[NB_BATCH];
-            nb_fetch(h, k0, cd, j);
-#pragma unroll
-            for (int u = 0; u < NB_BATCH; ++u) {
-                r[u] = gat(PV, j[u]);
-                rho[u] = gat(density, j[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < NB_BATCH; ++u) {
-                const bool live = k0 + u < cd;
-                const float dx = r[u].x - pvi.x, dy = r[u].y - pvi.y;
+        struct Rec {
+            float4 pv;
+            float rho;
+        };
+        nb_traverse(
+            h, cd, [&](uint32_t slot) { return Rec{gat(PV, slot), gat(density, slot)}; },
+            [&](const Rec& r, uint32_t k) {
+                const float dx = r.pv.x - pvi.x, dy = r.pv.y - pvi.y;
                 const float r_sq = dx * dx + dy * dy;
-                const float f = em * poly6_eval(K, r_sq) / (rho[u] * dt);
-                const float tx = ax + f * (r[u].z - pvi.z), ty = ay + f * (r[u].w - pvi.w);
-                ax = live ? tx : ax;
-                ay = live ? ty : ay;
-            }
-        }
+                const float f = em * poly6_eval(K, r_sq) / (r.rho * dt);
+                const float tx = ax + f * (r.pv.z - pvi.z), ty = ay + f * (r.pv.w - pvi.w);
+                ax = k < cd ? tx : ax;
+                ay = k < cd ? ty : ay;
+            });
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
     const uint32_t m = block_max_u32(__float_as_uint(vsq));
     __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&partials[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[xcd_bid()], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = arrive_is_last(scal) ? 1u : 0u;
     }
     __syncthreads();
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
 
 // a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524)
 __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     float4 pv = PV[i];
     const float2 a = accel[i];
@@ -1035,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
                                                         DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
         const NbHead h = nb_head(nb, i, soff);
@@ -1044,21 +1051,15 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
-            for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
-                uint32_t j[NB_BATCH];
-                float4 r[NB_BATCH];
-                nb_fetch(h, k0, ct, j);
-#pragma unroll
-                for (int u = 0; u < NB_BATCH; ++u) r[u] = gat(PV, j[u]);
-#pragma unroll
-                for (int u = 0; u < NB_BATCH; ++u) {
-                    const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+            nb_traverse(
+                h, ct, [&](uint32_t slot) { return gat(PV, slot); },
+                [&](const float4& r, uint32_t k) {
+                    const float2 g = wendland_grad(K, ri, make_float2(r.x, r.y));
                     // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
-                    const float dvx = pvi.z - r[u].z, dvy = pvi.w - r[u].w;
+                    const float dvx = pvi.z - r.z, dvy = pvi.w - r.w;
                     const float t = delta + (dvx * g.x + dvy * g.y);
-                    delta = (k0 + u < ct) ? t : delta;
-                }
-            }
+                    delta = k < ct ? t : delta;
+                });
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
     const double bs = block_sum_f64((double)e_owned);
     __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
-        __hip_atomic_store((unsigned long long*)&partials[blockIdx.x], (unsigned long long)__double_as_longlong(bs), __ATOMIC_RELAXED,
+        __hip_atomic_store((unsigned long long*)&partials[xcd_bid()], (unsigned long long)__double_as_longlong(bs), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         last_s = arrive_is_last(scal) ? 1u : 0u;
     }
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
 template <bool WARM, bool INV_DT>
 __global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     const NbHead h = nb_head(nb, i, soff);
     const uint32_t cd = h.cd, ct = h.ct;
@@ -1114,32 +1115,26 @@ __global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const 
         ri = make_float2(pki.x, pki.y);
     }
     float dx = 0.0f, dy = 0.0f;
-    for (uint32_t k0 = 0; k0 < ct; k0 += NB_BATCH) {
-        uint32_t j[NB_BATCH];
-        float4 r[NB_BATCH];
-        float wj[NB_BATCH];
-        nb_fetch(h, k0, ct, j);
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) {
-            const uint32_t idx = j[u];
-            if (WARM) {
-                r[u] = gat((const float4*)PV, idx);
-                wj[u] = gat((const float*)warm, idx < soff ? idx : i);  // warm[] has no boundary tail; static entries do not use it
-            } else {
-                r[u] = gat(PK, idx);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) {
-            const float2 g = wendland_grad(K, ri, make_float2(r[u].x, r[u].y));
+    struct Rec {
+        float4 r;
+        float w;
+    };
+    nb_traverse(
+        h, ct,
+        [&](uint32_t slot) {
+            // warm[] has no boundary tail; static entries do not use it
+            if (WARM) return Rec{gat((const float4*)PV, slot), gat((const float*)warm, slot < soff ? slot : i)};
+            return Rec{gat(PK, slot), 0.0f};
+        },
+        [&](const Rec& q, uint32_t k) {
+            const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
             // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
-            const float kj = WARM ? 0.5f * fmaxf(wj[u], lim) : r[u].z;
-            const float s = (k0 + u < cd) ? ki + kj : ki;
+            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
+            const float s = k < cd ? ki + kj : ki;
             const float tx = dx + s * g.x, ty = dy + s * g.y;
-            dx = (k0 + u < ct) ? tx : dx;
-            dy = (k0 + u < ct) ? ty : dy;
-        }
-    }
+            dx = k < ct ? tx : dx;
+            dy = k < ct ? ty : dy;
+        });
     float2 o;
     if (INV_DT) {
         o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
