@@ -72,6 +72,7 @@ def main():
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
     ap.add_argument("--lists-32bit", action="store_true", help="disable the 16-bit neighbour-list compression (A/B runs)")
+    ap.add_argument("--no-device-dt", action="store_true", help="plain sphx_step_begin: the device waits for the host's dt (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +118,7 @@ def main():
         n = n_global
 
         def one_step():
-            vmax = ctx.step_begin(timer.simulation_step())
+            vmax = ctx.step_begin(timer.simulation_step(), None if args.no_device_dt else timer.law(diam))
             dt_ns = timer.update_simulation_step(diam, vmax)
             return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
 

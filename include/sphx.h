@@ -126,6 +126,24 @@ int sphx_clear_cached(sphx_ctx* ctx);
 int sphx_step_begin(sphx_ctx* ctx, float dt_prev, float* out_vmax);
 int sphx_step_finish(sphx_ctx* ctx, float dt, sphx_step_stats* out_stats);
 
+/* The law the caller's TimeManager is about to apply to vmax (TimeManager::update_simulation_step, timemanager.rs:252-279,
+ * with the public TimerConfig of timemanager.rs:10-60 and the current TimeManager::simulation_step()).  Handing it to phase A
+ * lets the device derive the same dt right behind its vmax reduction and put the start of phase B (velocity prediction, first
+ * constant-density iteration) on the stream before the host has even read vmax: the GPU no longer idles for the host round trip.
+ * The host side is unchanged — it still calls update_simulation_step with *out_vmax and passes the result to
+ * sphx_step_finish, which verifies bit for bit that both arrived at the same dt (SPHX_ERR_INVALID_ARGUMENT otherwise; the
+ * device state is then stale and must be uploaded again). */
+typedef struct sphx_timer_law {
+    uint32_t adaptive;            /* SimulationStepConfig::Adaptive (1) or ::Fixed (0: dt stays simulation_step_ns) */
+    float cfl_factor;             /* AdaptiveTimeStep cfl factor (main.rs:126) */
+    float particle_diameter;      /* 2 * particle_radius (dfsph.rs:479) */
+    uint32_t reserved;
+    uint64_t timestep_min_ns;     /* main.rs:124 */
+    uint64_t timestep_max_ns;     /* main.rs:123 */
+    uint64_t simulation_step_ns;  /* TimeManager::simulation_step() before the update, in nanoseconds */
+} sphx_timer_law;
+int sphx_step_begin_law(sphx_ctx* ctx, float dt_prev, const sphx_timer_law* law, float* out_vmax); /* law == NULL: sphx_step_begin */
+
 /* ---- pieces of the path the reference exposes on FluidParticleWorld (driven by benches/) --------------------- */
 /* FluidParticleWorld::update_neighborhood_datastructure(vec![], vec![]) (fluidparticleworld.rs:235-261) */
 int sphx_update_neighborhood(sphx_ctx* ctx);
@@ -235,6 +253,7 @@ uint64_t sphx_timer_simulation_step_ns(const sphx_timer* t);                    
 uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float particle_diameter, float max_velocity); /* timemanager.rs:252-279 */
 uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t);
 uint32_t sphx_timer_num_steps(const sphx_timer* t);
+int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_law* out); /* fills sphx_timer_law from the mirror */
 
 /* DFSPHSolver::new(XSPHViscosityModel::new(h), h) boxed as dyn Solver (main.rs:93-101).  `params` may be NULL (defaults from the world). */
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out);

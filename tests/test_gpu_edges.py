@@ -23,7 +23,7 @@ def pair(pos, boundary=None, vel=None):
 
 
 def step_both(ctx, o, timer, check=True):
-    vmax = ctx.step_begin(timer.simulation_step())
+    vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
     dt_ns = timer.update_simulation_step(np.float32(0.01), vmax)
     st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
     so = o.dfsph_step()

@@ -86,12 +86,14 @@ def test_update_densities_bench_world(kind):
     assert_bits_equal(ctx.download_solver_state()["alpha"], o.alpha(), "alpha")
 
 
-def run_steps(ctx, o, steps, check_every=1):
+def run_steps(ctx, o, steps, check_every=1, use_law=True):
+    """use_law: sphx_step_begin_law — the device derives dt from its own vmax and runs ahead of the host; step_finish fails
+    unless the host timer arrives at the same bits, so every step also checks the device restatement of the timer law."""
     timer = y.TimeManager()
     diam = np.float32(2.0) * np.float32(0.005)
     for s in range(steps):
         dt_prev = timer.simulation_step()
-        vmax = ctx.step_begin(dt_prev)
+        vmax = ctx.step_begin(dt_prev, timer.law(diam) if use_law else None)
         dt_ns = timer.update_simulation_step(diam, vmax)
         st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
         so = o.dfsph_step()
@@ -128,6 +130,42 @@ def test_dfsph_dam_break_fixed_iterations():
     pos, boundary = dam_break(1.0)
     ctx, o = make_pair(pos, boundary, fixed=(3, 2))
     run_steps(ctx, o, 60, check_every=10)
+
+
+def test_dfsph_host_driven_dt():
+    """Plain sphx_step_begin (the device waits for the host's dt): same results as the run-ahead path."""
+    pos, boundary = dam_break(1.0)
+    ctx, o = make_pair(pos, boundary)
+    run_steps(ctx, o, 250, check_every=50, use_law=False)
+
+
+def test_timer_law_mismatch_is_detected():
+    """A law that is not the one the host timer applies: step_finish refuses the host's dt and asks for a new upload."""
+    pos, boundary = dam_break(1.0)
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    diam = np.float32(0.01)
+    for _ in range(150):  # into the CFL-limited regime, where the cfl factor matters
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+        ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+    law = timer.law(diam)
+    law.cfl_factor = 0.5
+    vmax = ctx.step_begin(timer.simulation_step(), law)
+    dt = y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax))
+    with pytest.raises(y.SphxError) as e:
+        ctx.step_finish(dt)
+    assert e.value.code == y._lib.ERR_INVALID_ARGUMENT
+    with pytest.raises(y.SphxError):
+        ctx.step_begin(timer.simulation_step())  # not ready until the state is uploaded again
+    ctx.upload(pos)
+    ctx.step_begin(timer.simulation_step())
+    ctx.step_finish(dt)
+    # a fixed-step timer goes through the same path
+    ft = y.TimeManager(fixed_ns=500_000)
+    vmax = ctx.step_begin(ft.simulation_step(), ft.law(diam))
+    ctx.step_finish(y.duration_as_secs_f32(ft.update_simulation_step(diam, vmax)))
 
 
 @pytest.mark.parametrize("span", [y.LISTS_32BIT, 150, 1000])

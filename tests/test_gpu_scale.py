@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def step(ctx, timer, diam=np.float32(0.01)):
-    vmax = ctx.step_begin(timer.simulation_step())
+    vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
     dt_ns = timer.update_simulation_step(diam, vmax)
     return ctx.step_finish(y.duration_as_secs_f32(dt_ns)), dt_ns
 

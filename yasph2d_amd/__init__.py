@@ -88,9 +88,14 @@ class SphxContext:
     def clear_cached(self):
         self._chk(self.L.sphx_clear_cached(self.h))
 
-    def step_begin(self, dt_prev):
+    def step_begin(self, dt_prev, law=None):
+        """Phase A.  law (TimeManager.law(diameter)): the device derives dt itself and starts phase B without waiting for the
+        host (sphx_step_begin_law); step_finish then verifies the host's dt against it."""
         v = C.c_float()
-        self._chk(self.L.sphx_step_begin(self.h, dt_prev, C.byref(v)))
+        if law is None:
+            self._chk(self.L.sphx_step_begin(self.h, dt_prev, C.byref(v)))
+        else:
+            self._chk(self.L.sphx_step_begin_law(self.h, dt_prev, C.byref(law), C.byref(v)))
         return v.value
 
     def step_finish(self, dt):
@@ -293,6 +298,14 @@ class TimeManager:
 
     def update_simulation_step(self, particle_diameter, max_velocity):
         return self.L.sphx_timer_update_simulation_step(self.h, particle_diameter, max_velocity)
+
+    def law(self, particle_diameter):
+        """sphx_timer_law for SphxContext.step_begin: this timer's config and current step."""
+        out = _lib.SphxTimerLaw()
+        rc = self.L.sphx_timer_law_of(self.h, particle_diameter, C.byref(out))
+        if rc:
+            raise SphxError(rc, "sphx_timer_law_of")
+        return out
 
     @property
     def total_simulated_ns(self):

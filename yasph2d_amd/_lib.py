@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsphx.so")
+# SPHX_LIB: load another build of the same library (kernel A/B experiments, tools/ab_build.sh)
+LIB_PATH = os.environ.get("SPHX_LIB") or os.path.join(_HERE, "libsphx.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (sphx.h)
@@ -31,6 +32,18 @@ class SphxParams(C.Structure):
         ("device", C.c_int32),
         ("list_span_limit", C.c_uint32),
         ("reserved", C.c_uint32 * 3),
+    ]
+
+
+class SphxTimerLaw(C.Structure):
+    _fields_ = [
+        ("adaptive", C.c_uint32),
+        ("cfl_factor", C.c_float),
+        ("particle_diameter", C.c_float),
+        ("reserved", C.c_uint32),
+        ("timestep_min_ns", C.c_uint64),
+        ("timestep_max_ns", C.c_uint64),
+        ("simulation_step_ns", C.c_uint64),
     ]
 
 
@@ -83,6 +96,8 @@ SIGNATURES = {
     "sphx_num_boundary": (_u32, [_vp]),
     "sphx_clear_cached": (_i, [_vp]),
     "sphx_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
+    "sphx_step_begin_law": (_i, [_vp, _f, _vp, _vp]),
+    "sphx_timer_law_of": (_i, [_vp, _f, _vp]),
     "sphx_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
     "sphx_update_neighborhood": (_i, [_vp]),
     "sphx_update_densities": (_i, [_vp, _i]),

@@ -202,6 +202,15 @@ Duration TimeManager::update_simulation_step(Real particle_diameter, Real max_ve
     }
     return simulation_step_;
 }
+void timer_law_of(const TimeManager& tm, Real particle_diameter, sphx_timer_law* out) {
+    out->adaptive = tm.fixed ? 0u : 1u;
+    out->cfl_factor = tm.fixed ? 1.0f : tm.cfl_factor;
+    out->particle_diameter = particle_diameter;
+    out->reserved = 0;
+    out->timestep_min_ns = tm.fixed ? tm.simulation_step_.ns : tm.timestep_min.ns;
+    out->timestep_max_ns = tm.fixed ? tm.simulation_step_.ns : tm.timestep_max.ns;
+    out->simulation_step_ns = tm.simulation_step_.ns;
+}
 void TimeManager::on_step_started() {
     num_simulation_steps += 1;
     total_simulated_time.ns += simulation_step_.ns;
@@ -261,7 +270,10 @@ void HipDfsphSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {  
     }
     const Real dt_prev = tm.simulation_step().as_secs_f32();  // dfsph.rs:433
     Real vmax = 0;
-    if ((rc = sphx_step_begin(ctx_, dt_prev, &vmax))) return fail(rc);
+    // the law the timer is about to apply (public TimerConfig, timemanager.rs:175): the device starts phase B with it right away
+    sphx_timer_law law;
+    timer_law_of(tm, w.properties.particle_radius() * 2.0f, &law);
+    if ((rc = sphx_step_begin_law(ctx_, dt_prev, use_timer_law ? &law : nullptr, &vmax))) return fail(rc);
     const Real dt = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // dfsph.rs:478-480
     if ((rc = sphx_step_finish(ctx_, dt, &last_stats))) return fail(rc);
     last_status = SPHX_OK;
@@ -367,6 +379,11 @@ uint64_t sphx_timer_simulation_step_ns(const sphx_timer* t) { return t->t.simula
 uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float diameter, float vmax) { return t->t.update_simulation_step(diameter, vmax).ns; }
 uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t) { return t->t.total_simulated_time.ns; }
 uint32_t sphx_timer_num_steps(const sphx_timer* t) { return t->t.num_simulation_steps; }
+int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_law* out) {
+    if (!t || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    sph::timer_law_of(t->t, particle_diameter, out);
+    return SPHX_OK;
+}
 
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out) {
     if (!w || !out) return SPHX_ERR_INVALID_ARGUMENT;

@@ -90,6 +90,9 @@ struct TimeManager {
     void on_step_started();  // the clock part of simulation_frame_loop (:244-247)
 };
 
+// what sphx_step_begin_law needs to know about the timer (its public config + current step)
+void timer_law_of(const TimeManager& tm, Real particle_diameter, sphx_timer_law* out);
+
 // solver/mod.rs:12-18
 struct Solver {
     virtual ~Solver() {}
@@ -108,6 +111,7 @@ class HipDfsphSolver : public Solver {
     int sync_world(FluidParticleWorld& fluid_world);  // download positions/velocities/densities into the host world
 
     bool sync_every_step = true;   // main.rs draws from the host arrays after each step
+    bool use_timer_law = true;     // sphx_step_begin_law: the device derives dt itself, the host only verifies it
     int last_status = SPHX_OK;     // the trait returns (); failures (reference: panics) are reported here
     std::string last_error;
     sphx_step_stats last_stats{};

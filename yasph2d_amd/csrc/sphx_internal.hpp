@@ -73,7 +73,8 @@ struct DevScalars {
     uint32_t flags;        // DF_*
     uint32_t ticket;       // second-level arrival counter (one arrival per stripe); reset by the last arriver
     uint32_t sort_total;   // number of particles that received a cell in the latest histogram scan (tile mode: new local count)
-    uint32_t pad[29];
+    float dt;              // time step the device derived from vmax with the host's timer law (sphx_step_begin_law)
+    uint32_t pad[28];
     Stripe stripe[STRIPES];
 };
 
@@ -87,7 +88,15 @@ struct Mailbox {
     unsigned long long nb_entries;
     unsigned long long owned_cum;
     uint32_t sort_total;
-    uint32_t pad2;
+    uint32_t dt_bits;       // sphx_step_begin_law: the device's dt (float bits) ...
+    unsigned long long dt_ns;  // ... and the Duration it came from
+};
+
+// TimeManager::update_simulation_step (timemanager.rs:252-279) as the device applies it to its own vmax
+struct TimerLaw {
+    uint32_t enabled, adaptive;
+    float cfl_factor, particle_diameter;
+    unsigned long long min_ns, max_ns, step_ns;
 };
 
 struct Grid {
@@ -154,6 +163,9 @@ struct sphx_ctx {
     uint32_t* nb_list = nullptr;
     uint32_t* nb_counts = nullptr;  // format << 31 | count_total << 16 | count_dynamic
     uint2* nb_bases = nullptr;
+    // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
+    uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
+    bool law_active = false;
     sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_bases}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;

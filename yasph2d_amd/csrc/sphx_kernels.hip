@@ -856,7 +856,12 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
 // neighbour traversal: loads are issued in batches of NB_BATCH (indices, then records) so several gathers are in flight per
 // lane; the accumulation stays sequential in list order.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TRAV_BOUNDS
+#define TRAV_BOUNDS __launch_bounds__(256)
+#endif
+#ifndef NB_BATCH
 #define NB_BATCH 4
+#endif
 
 // Compressed lists (neighborhood_search.rs:262-273 sketches the idea; README.md:12 calls it WIP).  The entries of one particle
 // are ascending sorted-array indices out of its 3x3 cell box, so they sit within a short span above the first candidate: a
@@ -971,12 +976,48 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     if (ALPHA) alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);     // dfsph.rs:94
 }
 
+// std::time::Duration::from_secs_f32 as restated in sphx_host.cpp (round to nearest nanosecond, ties to even): the 24-bit
+// mantissa times 1e9 fits in 54 bits, so 64-bit arithmetic is exact here
+__device__ __forceinline__ unsigned long long duration_from_secs_f32(float secs) {
+    if (!(secs >= 0.0f) || secs > 3.0e9f) return ~0ull;  // the host rejects these before it gets here
+    const uint32_t bits = __float_as_uint(secs);
+    const uint32_t bexp = (bits >> 23) & 0xFFu;
+    unsigned long long mant = bits & 0x7FFFFFu;
+    int exp2;
+    if (bexp == 0) {
+        exp2 = -149;
+    } else {
+        mant |= 0x800000ull;
+        exp2 = (int)bexp - 150;
+    }
+    const unsigned long long num = mant * 1000000000ull;
+    if (exp2 >= 0) return num << exp2;  // secs <= 3e9 < 2^32: exp2 <= 8, no overflow
+    const int sh = -exp2;
+    if (sh >= 55) return 0ull;
+    const unsigned long long q = num >> sh;
+    const unsigned long long rem = num - (q << sh);
+    const unsigned long long half = 1ull << (sh - 1);
+    return q + ((rem > half || (rem == half && (q & 1ull))) ? 1ull : 0ull);
+}
+__device__ __forceinline__ float duration_as_secs_f32(unsigned long long ns) {
+    const unsigned long long secs = ns / 1000000000ull;
+    const uint32_t nanos = (uint32_t)(ns % 1000000000ull);
+    return (float)secs + (float)nanos / 1000000000.0f;
+}
+// TimeManager::update_simulation_step, timemanager.rs:252-279 (AdaptiveTimeStepTarget::None, main.rs:125)
+__device__ __forceinline__ unsigned long long timer_law_step_ns(const TimerLaw& law, float vmax) {
+    if (!law.adaptive) return law.step_ns;
+    const unsigned long long cfl_ns = duration_from_secs_f32(law.cfl_factor * 0.4f * law.particle_diameter / (vmax + 0.00001f));
+    const unsigned long long upper = min(law.max_ns, law.step_ns * 2ull);
+    return max(law.min_ns, min(upper, cfl_ns));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
+__global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
-                                                      Mailbox* __restrict__ mb, uint32_t seq) {
+                                                      Mailbox* __restrict__ mb, uint32_t seq, TimerLaw law) {
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     float vsq = 0.0f;
     if (i < n) {
@@ -1017,13 +1058,25 @@ __global__ __launch_bounds__(256) void k_nonpressure(const float4* __restrict__ 
         b = block_max_u32(b);
         if (threadIdx.x == 0) {
             mb->vmax_sq_bits = b;
+            if (law.enabled) {
+                // the step the host's TimeManager will arrive at (dfsph.rs:478-480): the kernels queued behind this one read it
+                // from scal->dt instead of waiting for the host round trip
+                const unsigned long long ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
+                const float dt_new = duration_as_secs_f32(ns);
+                __hip_atomic_store((uint32_t*)&scal->dt, __float_as_uint(dt_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mb->dt_ns = ns;
+                mb->dt_bits = __float_as_uint(dt_new);
+            }
             publish_common(scal, mb, seq);
         }
     }
 }
 
 // a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524)
-__global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt) {
+// dt_dev (all kernels that take it): the step derived on the device (TimerLaw); nullptr = use the host's argument
+__global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt,
+                                                  const float* __restrict__ dt_dev) {
+    if (dt_dev) dt = *dt_dev;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     float4 pv = PV[i];
@@ -1038,10 +1091,12 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
 // k_i = err_i * alpha_i the correction step needs (dfsph.rs:141,150 / :295,304), and the residual sum (dfsph.rs:221 / :377)
 // ------------------------------------------------------------------------------------------------------------------
 template <bool DIVERGENCE>
-__global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
+__global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
-                                                        DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
+                                                        DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq,
+                                                        const float* __restrict__ dt_dev) {
+    if (dt_dev) dt = *dt_dev;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
@@ -1097,8 +1152,10 @@ __global__ __launch_bounds__(256) void k_compute_error(const float4* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 // WARM=false: k comes from PK (own and neighbours'), warm[i] += k_i.   WARM=true: k = 0.5*max(warm, lim) (clamp applied on read).
 template <bool WARM, bool INV_DT>
-__global__ __launch_bounds__(256) void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
-                                                  uint32_t soff, Consts K, float inv_dt, float lim, NbView nb) {
+__global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
+                                                  uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
+                                                  const float* __restrict__ dt_dev) {
+    if (dt_dev) inv_dt = 1.0f / *dt_dev;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     const NbHead h = nb_head(nb, i, soff);
