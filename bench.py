@@ -192,12 +192,15 @@ def main():
         # HBM traffic of that kernel from the PMC counters: cannot be collected from inside the process; taken from the committed
         # rocprofv3 passes of this same command (profiles/) when the workload matches, else null.
         traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_1M.json")))
-            if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
-                traffic, traffic_src = tj["bytes_per_launch"][name]["total"], tj["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+        import glob
+
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_traffic_*.json"))):
+            try:
+                tj = json.load(open(tf))
+                if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
+                    traffic, traffic_src = tj["bytes_per_launch"][name]["total"], tj["source"]
+            except (OSError, KeyError, ValueError):
+                pass
         roof = {
             "bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "launches": rec["launches"],

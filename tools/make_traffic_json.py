@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""profiles/<prefix>_traffic_<tag>.json from the FETCH_SIZE / WRITE_SIZE tables of tools/summarize_profile.py (separate rocprofv3
+passes of `python3 bench.py ...`).  bench.py reads it for roofline.traffic (the counters cannot be read from inside the process).
+
+usage: make_traffic_json.py fetch.txt write.txt particles out.json "source text"
+"""
+import json
+import sys
+
+NAMES = {  # kernel symbol -> bench.py's launch label
+    "k_neighbor_build<true>": "neighbor_build+density_alpha", "k_nonpressure": "nonpressure_accel_vmax",
+    "k_compute_error<false>": "compute_density_error", "k_compute_error<true>": "compute_density_change",
+    "k_correct<false, true>": "correct_velocity_with_density_error", "k_correct<false, false>": "correct_velocity_with_divergence_error",
+    "k_correct<true, true>": "correct_density_error_warmstart", "k_correct<true, false>": "correct_divergence_error_warmstart",
+    "k_rank_gather": "gather_attributes", "k_key_count<true>": "advect+cell_count", "k_predict": "velocity_prediction", "k_scatter": "cell_scatter",
+}
+
+
+def table(path):
+    out = {}
+    for line in open(path):
+        parts = line.rstrip().split()
+        if len(parts) >= 5 and parts[-1].replace(".", "").isdigit() and parts[-2].isdigit():
+            name = " ".join(parts[:-4])
+            out[name] = int(parts[-2])
+    return out
+
+
+fetch, write = table(sys.argv[1]), table(sys.argv[2])
+res = {}
+for k, label in NAMES.items():
+    if k in fetch or k in write:
+        f, w = fetch.get(k, 0), write.get(k, 0)
+        res[label] = {"fetch": f, "write": w, "total": f + w}
+scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0), "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0)}
+scan["total"] = scan["fetch"] + scan["write"]
+res["cell_scan"] = scan
+json.dump({"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(res, indent=1)[:400])

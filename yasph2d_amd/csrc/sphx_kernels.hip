@@ -696,7 +696,8 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
     __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
-    __shared__ float2 win[256 + 2 * WIN_HALO];  // positions of the sorted particles around this workgroup's 256
+    __shared__ float2 win[256 + 2 * WIN_HALO + 1];  // positions of the sorted particles around this workgroup's 256 (+1: the
+                                                    // pipelined read one past a cell's last candidate stays inside the array)
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
     for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
     __syncthreads();
     uint32_t cd = 0, ct = 0;
-    uint32_t wide = 0, lo_d = 0xFFFFFFFFu, lo_s = 0xFFFFFFFFu;  // list format of this wave (see NbHead), bases of the 16-bit offsets
+    uint32_t wide = 0, lo_d = 0, lo_s = 0;  // list format of this wave (see NbHead), bases of the 16-bit offsets
     uint16_t* const lp16 = (uint16_t*)(list + (size_t)(i >> 6) * 4096) + lane;
     float2 pi = make_float2(0.0f, 0.0f);
     if (i < n) {
@@ -736,15 +737,16 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
         uint32_t s[9], e[9];
         lookup9(gd, c, s, e);
-        uint32_t far = 0;  // OR of all (entry - base) offsets: decides the list format of rows 0..STAGE_ROWS-1 at flush time
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // software pipeline: the next candidate's ds_read is in flight while the current one is tested
-            float2 pn = lds_read_f2(&win[min(s[t] - w0, wlen - 1u)]);
+            // software pipeline: the next candidate's ds_read is in flight while the current one is tested.  The out-of-window
+            // re-read stays INSIDE the loop: per (lane, cell) it is rare, but some lane of a wave needs it for most cells, and a
+            // separate slow loop would then run after the fast one for nearly every wave (measured: +5 us).
+            float2 pn = lds_read_f2(&win[min(s[t] - w0, wlen)]);
             for (uint32_t j = s[t]; j < e[t]; ++j) {
                 const uint32_t wj = j - w0;
-                float2 pj = pn;  // always from LDS; the rare out-of-window candidate re-reads from global
-                pn = lds_read_f2(&win[min(wj + 1u, wlen - 1u)]);
+                float2 pj = pn;
+                pn = lds_read_f2(&win[min(wj + 1u, wlen)]);  // win[wlen] is the pad slot
                 if (wj >= wlen) pj = gat(posA, j);
                 const float dx = pj.x - pi.x, dy = pj.y - pi.y;
                 const float d2 = dx * dx + dy * dy;
@@ -753,8 +755,6 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                         mytile[ct * 64] = j;
                     else
                         list[ell_index(i, ct)] = j;
-                    lo_d = min(lo_d, j);  // ascending: the first accepted entry
-                    far |= j - lo_d;
                     ct += 1;
                 }
             }
@@ -783,8 +783,6 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
                             mytile[ct * 64] = j;
                         else
                             list[ell_index(i, ct)] = j;
-                        lo_s = min(lo_s, j);
-                        far |= j - lo_s;
                         ct += 1;
                     }
                 }
@@ -792,6 +790,17 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         }
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
+        // List format of the staged rows (NbHead): entries ascend, so the first and the last staged entry of each part bound
+        // every 16-bit offset.  Own column of the tile, written by this lane: no barrier needed.
+        uint32_t far = 0;
+        if (cd) {
+            lo_d = mytile[0];
+            far = mytile[(min(cd, STAGE_ROWS) - 1u) * 64] - lo_d;
+        }
+        if (ct > cd && cd < STAGE_ROWS) {
+            lo_s = mytile[cd * 64];
+            far |= mytile[(min(ct, STAGE_ROWS) - 1u) * 64] - lo_s;
+        }
         wide = __any(far >= K.span_limit) ? 1u : 0u;
         counts[i] = (wide << 31) | (ct << 16) | cd;
         bases[i] = make_uint2(lo_d, soff + lo_s);
