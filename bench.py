@@ -72,6 +72,8 @@ def main():
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
     ap.add_argument("--lists-32bit", action="store_true", help="disable the 16-bit neighbour-list compression (A/B runs)")
+    ap.add_argument("--solver", default="dfsph", choices=["dfsph", "wcsph"],
+                    help="wcsph: the second Solver of the reference (solver/wscsph.rs, cfl factor 0.2, main.rs:116-119) on one GPU")
     ap.add_argument("--no-device-dt", action="store_true", help="plain sphx_step_begin: the device waits for the host's dt (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -106,18 +108,23 @@ def main():
     pos, boundary = w.positions, w.boundary_particles
     n_global = len(pos)
     diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
-    timer = y.TimeManager()
+    timer = y.TimeManager(cfl_factor=0.2) if args.solver == "wcsph" else y.TimeManager()
     params = y.default_params(device=dev_index)
     if args.lists_32bit:
         params.list_span_limit = y.LISTS_32BIT
     ctx = y.SphxContext(params)
 
+    if args.solver == "wcsph" and (world > 1 or args.force_tiles):
+        raise SystemExit("--solver wcsph runs on one GPU")
     if world == 1 and not args.force_tiles:
         ctx.set_boundary(boundary)
         ctx.upload(pos)
         n = n_global
 
         def one_step():
+            if args.solver == "wcsph":
+                vmax = ctx.wcsph_step_begin(timer.simulation_step())
+                return ctx.wcsph_step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
             vmax = ctx.step_begin(timer.simulation_step(), None if args.no_device_dt else timer.law(diam))
             dt_ns = timer.update_simulation_step(diam, vmax)
             return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
@@ -214,7 +221,7 @@ def main():
         bstep_ref = bytes_per_particle_step(kb, Id, Iv, Wd, Wv)
         bstep = bytes_per_particle_step(kb, Id, Iv, Wd, Wv, compressed=not args.lists_32bit)
         out = {
-            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break",
+            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break" if args.solver == "dfsph" else "particle-steps/sec, 2D WCSPH dam-break",
             "value": value,
             "unit": "particle-steps/s",
             "n_gpus": world,
@@ -227,7 +234,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"DFSPH 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
+                "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
                             f"in total ({n} fluid per GPU), adaptive CFL timer from t=0, two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "particles_total": n_global,
@@ -244,7 +251,7 @@ def main():
         }
         if roof:
             out["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.solver == "dfsph":
             out["cpu_baseline"] = cpu_baseline(pos, boundary)
         print(json.dumps(out))
     if dist is not None:

@@ -144,6 +144,18 @@ typedef struct sphx_timer_law {
 } sphx_timer_law;
 int sphx_step_begin_law(sphx_ctx* ctx, float dt_prev, const sphx_timer_law* law, float* out_vmax); /* law == NULL: sphx_step_begin */
 
+/* WCSPHSolver::simulation_step (solver/wscsph.rs:126-179), the second Solver behind the same boundary,
+ * two-phase for the same reason:
+ *   phase A = leap frog 1 with dt = time_manager.simulation_step() (:138-149), update_neighborhood_datastructure (:152),
+ *             update_densities(Poly6) (:153), update_accellerations (:59-118, :154), max |v + a*dt| (:158-161) -> *out_vmax
+ *   host    = dt = time_manager.update_simulation_step(2*radius, vmax).as_secs_f32()   (:162-164)
+ *   phase B = leap frog 2 (:168-177)
+ * Constants as WCSPHSolver::new (:31-49): Poly6 density kernel, Spiky pressure kernel, XSPH viscosity, Tait gamma 7,
+ * set_compressibility(0.01, 1.0), boundary_force_factor 1.  sphx_clear_cached also drops the accelerations (:122-124).
+ * One context runs one solver: the DFSPH and the WCSPH step share the acceleration array. */
+int sphx_wcsph_step_begin(sphx_ctx* ctx, float dt, float* out_vmax);
+int sphx_wcsph_step_finish(sphx_ctx* ctx, float dt, sphx_step_stats* out_stats);
+
 /* ---- pieces of the path the reference exposes on FluidParticleWorld (driven by benches/) --------------------- */
 /* FluidParticleWorld::update_neighborhood_datastructure(vec![], vec![]) (fluidparticleworld.rs:235-261) */
 int sphx_update_neighborhood(sphx_ctx* ctx);
@@ -257,6 +269,7 @@ int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_l
 
 /* DFSPHSolver::new(XSPHViscosityModel::new(h), h) boxed as dyn Solver (main.rs:93-101).  `params` may be NULL (defaults from the world). */
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out);
+int sphx_solver_create_wcsph(const sphx_world* w, const sphx_params* params, sphx_solver** out); /* WCSPHSolver::new, wscsph.rs:29-42 */
 void sphx_solver_destroy(sphx_solver* s);
 void sphx_solver_clear_cached_data(sphx_solver* s); /* Solver::clear_cached_data */
 /* Solver::simulation_step(&mut world, &mut time_manager) (dfsph.rs:414).  sync_world != 0 copies positions/velocities/

@@ -15,7 +15,7 @@ from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_NEIGHBO
                    KERNEL_SPIKY, KERNEL_WENDLAND_C2, SphxError, SphxKernelTime, SphxParams, SphxStepStats)
 
 __all__ = ["SphxContext", "FluidParticleWorld", "TimeManager", "DFSPHSolver", "default_params", "duration_from_secs_f32",
-           "duration_as_secs_f32", "SphxError"]
+           "duration_as_secs_f32", "SphxError", "WCSPHSolver"]
 
 
 def _p(a):
@@ -101,6 +101,17 @@ class SphxContext:
     def step_finish(self, dt):
         st = SphxStepStats()
         self._chk(self.L.sphx_step_finish(self.h, dt, C.byref(st)))
+        return st.as_dict()
+
+    def wcsph_step_begin(self, dt):
+        """WCSPHSolver::simulation_step up to the timer call (wscsph.rs:126-161) -> vmax."""
+        v = C.c_float()
+        self._chk(self.L.sphx_wcsph_step_begin(self.h, dt, C.byref(v)))
+        return v.value
+
+    def wcsph_step_finish(self, dt):
+        st = SphxStepStats()
+        self._chk(self.L.sphx_wcsph_step_finish(self.h, dt, C.byref(st)))
         return st.as_dict()
 
     def update_neighborhood(self):
@@ -319,10 +330,12 @@ class TimeManager:
 class DFSPHSolver:
     """Box<dyn Solver> holding the HIP-backed DFSPHSolver (solver/mod.rs:12-18, dfsph.rs:405-526)."""
 
+    _create = "sphx_solver_create_dfsph"
+
     def __init__(self, world, params=None):
         self.L = _lib.lib()
         h = C.c_void_p()
-        rc = self.L.sphx_solver_create_dfsph(world.h, C.byref(params) if params is not None else None, C.byref(h))
+        rc = getattr(self.L, self._create)(world.h, C.byref(params) if params is not None else None, C.byref(h))
         if rc:
             raise SphxError(rc, self.L.sphx_last_error(None).decode())
         self.h = h
@@ -357,3 +370,9 @@ class DFSPHSolver:
         ctx._owned = False
         ctx.h = C.c_void_p(self.L.sphx_solver_ctx(self.h))
         return ctx
+
+
+class WCSPHSolver(DFSPHSolver):
+    """Box<dyn Solver> holding the HIP-backed WCSPHSolver (solver/wscsph.rs); the app pairs it with cfl_factor 0.2 (main.rs:116-119)."""
+
+    _create = "sphx_solver_create_wcsph"

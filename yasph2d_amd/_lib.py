@@ -155,6 +155,9 @@ SIGNATURES = {
     "sphx_timer_total_simulated_ns": (_u64, [_vp]),
     "sphx_timer_num_steps": (_u32, [_vp]),
     "sphx_solver_create_dfsph": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(_vp)]),
+    "sphx_solver_create_wcsph": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(_vp)]),
+    "sphx_wcsph_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
+    "sphx_wcsph_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
     "sphx_solver_destroy": (None, [_vp]),
     "sphx_solver_clear_cached_data": (None, [_vp]),
     "sphx_solver_simulation_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(SphxStepStats)]),

@@ -268,18 +268,33 @@ void HipDfsphSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {  
         uploaded_n_ = n;
         uploaded_generation_ = w.fluid_generation;
     }
+    if ((rc = device_step(w, tm))) return fail(rc);
+    last_status = SPHX_OK;
+    if (sync_every_step) {
+        if ((rc = sync_world(w))) return fail(rc);
+    }
+}
+
+int HipDfsphSolver::device_step(FluidParticleWorld& w, TimeManager& tm) {
+    int rc;
     const Real dt_prev = tm.simulation_step().as_secs_f32();  // dfsph.rs:433
     Real vmax = 0;
     // the law the timer is about to apply (public TimerConfig, timemanager.rs:175): the device starts phase B with it right away
     sphx_timer_law law;
     timer_law_of(tm, w.properties.particle_radius() * 2.0f, &law);
-    if ((rc = sphx_step_begin_law(ctx_, dt_prev, use_timer_law ? &law : nullptr, &vmax))) return fail(rc);
+    if ((rc = sphx_step_begin_law(ctx_, dt_prev, use_timer_law ? &law : nullptr, &vmax))) return rc;
     const Real dt = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // dfsph.rs:478-480
-    if ((rc = sphx_step_finish(ctx_, dt, &last_stats))) return fail(rc);
-    last_status = SPHX_OK;
-    if (sync_every_step) {
-        if ((rc = sync_world(w))) return fail(rc);
-    }
+    return sphx_step_finish(ctx_, dt, &last_stats);
+}
+
+// WCSPHSolver<XSPHViscosityModel>::simulation_step, wscsph.rs:126-179
+int HipWcsphSolver::device_step(FluidParticleWorld& w, TimeManager& tm) {
+    int rc;
+    const Real dt = tm.simulation_step().as_secs_f32();  // wscsph.rs:135
+    Real vmax = 0;
+    if ((rc = sphx_wcsph_step_begin(ctx_, dt, &vmax))) return rc;
+    const Real dt_new = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // wscsph.rs:162-164
+    return sphx_wcsph_step_finish(ctx_, dt_new, &last_stats);
 }
 
 int HipDfsphSolver::sync_world(FluidParticleWorld& w) {
@@ -310,8 +325,10 @@ struct sphx_timer {
     sph::TimeManager t;
 };
 struct sphx_solver {
-    sph::HipDfsphSolver s;
-    sphx_solver(const sph::FluidParticleWorld& w, const sphx_params* p) : s(w, p) {}
+    sph::HipDfsphSolver* sp;
+    sph::HipDfsphSolver& s;
+    sphx_solver(sph::HipDfsphSolver* p) : sp(p), s(*p) {}
+    ~sphx_solver() { delete sp; }
 };
 
 extern "C" {
@@ -387,11 +404,22 @@ int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_l
 
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out) {
     if (!w || !out) return SPHX_ERR_INVALID_ARGUMENT;
-    sphx_solver* s = new sphx_solver(w->w, params);
+    sphx_solver* s = new sphx_solver(new sph::HipDfsphSolver(w->w, params));
     if (!s->s.ok()) {
         const int rc = s->s.last_status;
         delete s;
         *out = nullptr;
+        return rc;
+    }
+    *out = s;
+    return SPHX_OK;
+}
+int sphx_solver_create_wcsph(const sphx_world* w, const sphx_params* params, sphx_solver** out) {
+    if (!w || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    sphx_solver* s = new sphx_solver(new sph::HipWcsphSolver(w->w, params));
+    if (!s->s.ok()) {
+        const int rc = s->s.last_status;
+        delete s;
         return rc;
     }
     *out = s;

@@ -117,10 +117,22 @@ class HipDfsphSolver : public Solver {
     sphx_step_stats last_stats{};
     sphx_ctx* ctx() { return ctx_; }
 
-   private:
+   protected:
+    virtual int device_step(FluidParticleWorld& fluid_world, TimeManager& time_manager);  // the two-phase step on the device
     sphx_ctx* ctx_ = nullptr;
+
+   private:
     uint64_t uploaded_generation_ = 0;
     size_t uploaded_n_ = (size_t)-1;
+};
+
+// WCSPHSolver<XSPHViscosityModel> (wscsph.rs:14-49) on the same device context type: same world handling, the WCSPH step
+class HipWcsphSolver : public HipDfsphSolver {
+   public:
+    using HipDfsphSolver::HipDfsphSolver;
+
+   protected:
+    int device_step(FluidParticleWorld& fluid_world, TimeManager& time_manager) override;
 };
 
 }  // namespace sph

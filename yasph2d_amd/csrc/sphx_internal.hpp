@@ -37,6 +37,8 @@ struct Consts {
     float sp_h, sp_norm, sp_ngrad;   // Spiky::new (spiky.rs:16-23)
     float mass, rho0, xsph_eps;
     float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
+    float gx, gy;    // gravity itself (wscsph.rs:83)
+    float wc_stiffness, wc_boundary_force;  // WCSPHSolver::set_compressibility(.., 0.01, 1.0), boundary_force_factor (wscsph.rs:31-49)
     // spatial tile owned by this context (multi-GPU): cells with tile_lo <= c < tile_hi along tile_axis; reductions only count
     // owned particles.  Single-GPU default: [0, 65536).
     uint32_t tile_axis, tile_lo, tile_hi;
@@ -166,6 +168,9 @@ struct sphx_ctx {
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
+    // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
+    uint32_t wcsph_n = 0;
+    bool in_wcsph = false;
     sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_bases}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;

@@ -1021,6 +1021,37 @@ __device__ __forceinline__ unsigned long long timer_law_step_ns(const TimerLaw& 
     return max(law.min_ns, min(upper, cfl_ns));
 }
 
+// max over all workgroups of a per-lane non-negative float, exact (non-negative floats order like their bit patterns); the last
+// workgroup to arrive publishes it to the mailbox — and, given a timer law, the dt the host's TimeManager will derive from it
+__device__ __forceinline__ void reduce_publish_vmax(float vsq, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
+                                                    Mailbox* __restrict__ mb, uint32_t seq, const TimerLaw& law) {
+    const uint32_t m = block_max_u32(__float_as_uint(vsq));
+    __shared__ uint32_t last_s;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[xcd_bid()], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = arrive_is_last(scal) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_s) {
+        uint32_t b = 0;
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) b = max(b, __hip_atomic_load(&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b = block_max_u32(b);
+        if (threadIdx.x == 0) {
+            mb->vmax_sq_bits = b;
+            if (law.enabled) {
+                // the step the host's TimeManager will arrive at (dfsph.rs:478-480): the kernels queued behind this one read it
+                // from scal->dt instead of waiting for the host round trip
+                const unsigned long long ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
+                const float dt_new = duration_as_secs_f32(ns);
+                __hip_atomic_store((uint32_t*)&scal->dt, __float_as_uint(dt_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mb->dt_ns = ns;
+                mb->dt_bits = __float_as_uint(dt_new);
+            }
+            publish_common(scal, mb, seq);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
@@ -1053,32 +1084,7 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
-    // exact max: non-negative floats order like their bit patterns
-    const uint32_t m = block_max_u32(__float_as_uint(vsq));
-    __shared__ uint32_t last_s;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&partials[xcd_bid()], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = arrive_is_last(scal) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last_s) {
-        uint32_t b = 0;
-        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) b = max(b, __hip_atomic_load(&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        b = block_max_u32(b);
-        if (threadIdx.x == 0) {
-            mb->vmax_sq_bits = b;
-            if (law.enabled) {
-                // the step the host's TimeManager will arrive at (dfsph.rs:478-480): the kernels queued behind this one read it
-                // from scal->dt instead of waiting for the host round trip
-                const unsigned long long ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
-                const float dt_new = duration_as_secs_f32(ns);
-                __hip_atomic_store((uint32_t*)&scal->dt, __float_as_uint(dt_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mb->dt_ns = ns;
-                mb->dt_bits = __float_as_uint(dt_new);
-            }
-            publish_common(scal, mb, seq);
-        }
-    }
+    reduce_publish_vmax(vsq, partials, scal, mb, seq, law);
 }
 
 // a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524)
@@ -1093,6 +1099,86 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
     pv.z = pv.z + a.x * dt;
     pv.w = pv.w + a.y * dt;
     PV[i] = pv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// WCSPH (solver/wscsph.rs): the second Solver behind the same boundary.  Reuses the grid, the neighbour
+// lists and k_density_alpha<Poly6>.
+// ------------------------------------------------------------------------------------------------------------------
+// leap frog 1, wscsph.rs:138-149: v += 0.5*dt*a (v at t+1/2), pos += v*dt
+__global__ __launch_bounds__(256) void k_wcsph_leapfrog1(float4* __restrict__ PV, float2* __restrict__ posA, const float2* __restrict__ accel,
+                                                          uint32_t n, float dt) {
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 pv = PV[i];
+    const float2 a = accel[i];
+    const float hdt = 0.5f * dt;
+    pv.z = pv.z + hdt * a.x;
+    pv.w = pv.w + hdt * a.y;
+    pv.x = pv.x + pv.z * dt;
+    pv.y = pv.y + pv.w * dt;
+    PV[i] = pv;
+    posA[i] = make_float2(pv.x, pv.y);
+}
+// f32::powi(x, 7) = compiler-rt __powisf2: square and multiply, in this order
+__device__ __forceinline__ float powi7(float a) {
+    float r = a;          // b = 7: r = 1 * a
+    a = a * a;            // a^2
+    r = r * a;            // b = 3
+    a = a * a;            // a^4
+    return r * a;         // b = 1
+}
+// Tait equation of state with pressure clamping, wscsph.rs:52-57
+__device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_density) {
+    return K.wc_stiffness * (powi7(fmaxf(local_density / K.rho0, 1.0f)) - 1.0f);
+}
+// update_accellerations (wscsph.rs:59-118) + max |v + a*dt|^2 (wscsph.rs:158-161)
+__global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
+                                          float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials,
+                                          DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    float vsq = 0.0f;
+    if (i < n) {
+        const float4 pvi = PV[i];
+        const float rhoi = density[i];
+        const NbHead h = nb_head(nb, i, soff);
+        const uint32_t cd = h.cd, ct = h.ct;
+        float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
+        const float pi = wcsph_pressure(K, rhoi);
+        struct Rec {
+            float4 pv;
+            float rho;
+        };
+        nb_traverse(
+            h, ct, [&](uint32_t slot) { return Rec{gat(PV, slot), gat(density, slot < soff ? slot : i)}; },  // density[] has no boundary tail
+            [&](const Rec& q, uint32_t k) {
+                const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
+                const float r_sq = dx * dx + dy * dy;
+                const float r = sqrtf(r_sq);
+                float tx, ty;
+                if (k < cd) {
+                    const float pj = wcsph_pressure(K, q.rho);
+                    const float pu = -K.mass * (pi + pj) / (2.0f * rhoi * q.rho);                   // wscsph.rs:99
+                    const float dd = fmaxf(K.sp_h - r, 0.0f);
+                    const float sg = K.sp_ngrad * dd * dd / (r + 1.0e-10f);                          // Spiky::gradient, spiky.rs:34-37
+                    tx = ax + pu * (sg * dx);
+                    ty = ay + pu * (sg * dy);
+                    const float f = K.xsph_eps * K.mass * poly6_eval(K, r_sq) / (q.rho * dt);        // xsph.rs:21-23
+                    tx = tx + f * (q.pv.z - pvi.z);
+                    ty = ty + f * (q.pv.w - pvi.w);
+                } else {
+                    const float s = K.wc_boundary_force * spiky_eval(K, r) / r_sq;                   // wscsph.rs:114
+                    tx = ax - s * dx;
+                    ty = ay - s * dy;
+                }
+                ax = k < ct ? tx : ax;
+                ay = k < ct ? ty : ay;
+            });
+        accel[i] = make_float2(ax, ay);
+        const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
+        vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;
+    }
+    reduce_publish_vmax(vsq, partials, scal, mb, seq, TimerLaw{});
 }
 
 // ------------------------------------------------------------------------------------------------------------------
