@@ -12,6 +12,7 @@ Files (numpy .npz, a few hundred KB in total):
   dam_break_4050_fixed.npz  same scene, fixed 3 density / 2 divergence iterations, after 20 steps
   bench_world.npz      benches/benchmarks/update_densities.rs world: sorted order, cells, neighbour lists, densities per kernel
   uniform_1000.npz     the neighbour-search test workload (1000 points, density 10, R = 1): sorted order + lists
+  wcsph_dam_break_4050.npz  WCSPH (solver/wscsph.rs, cfl factor 0.2) on the same scene: state after 1, 50, 300 steps
 """
 import hashlib
 import os
@@ -64,7 +65,27 @@ def dam(fixed, checkpoints, name):
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
+def wcsph(checkpoints, name):
+    import yasph2d_amd as y
+
+    pos, boundary = dam_break(1.0)
+    t = y.TimeManager(cfl_factor=0.2)
+    o = Oracle()
+    o.timer_adaptive(t.timestep_max_ns, t.timestep_min_ns, 0.2)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    out = dict(in_pos=pos, in_boundary=boundary, timestep_max_ns=np.uint64(t.timestep_max_ns), timestep_min_ns=np.uint64(t.timestep_min_ns))
+    for s in range(1, max(checkpoints) + 1):
+        o.wcsph_step()
+        if s in checkpoints:
+            c, _, l = o.neighbors()
+            out.update({f"s{s}_pos": o.positions(), f"s{s}_vel": o.velocities(), f"s{s}_density": o.densities(), f"s{s}_ids": o.ids(),
+                        f"s{s}_nb_digest": digest(c, l), f"s{s}_timer_ns": np.uint64(o.timer_step_ns())})
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 def main():
+    wcsph((1, 50, 300), "wcsph_dam_break_4050.npz")
     dam((0, 0), (1, 10, 100), "dam_break_4050.npz")
     dam((3, 2), (20,), "dam_break_4050_fixed.npz")
 
