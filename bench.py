@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--skip-steps", type=int, default=0,
+                    help="untimed steps before the warm-up (SURVEY 8(d): a second window after 2000 steps = the violent phase, high Id/Iv)")
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
@@ -162,7 +164,7 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.skip_steps + args.warmup):
         one_step()
 
     stats = []
@@ -235,7 +237,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
-                            f"in total ({n} fluid per GPU), adaptive CFL timer from t=0, two-phase step through the C ABI",
+                            f"in total ({n} fluid per GPU), adaptive CFL timer from t=0"
+                            + (f", window after {args.skip_steps} steps" if args.skip_steps else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
