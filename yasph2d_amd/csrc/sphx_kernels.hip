@@ -666,25 +666,48 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
     SPHX_CE(c2, c3)
 }
 
-// particle ranges of 9 (ascending) cell codes; the directory entry is re-read only when the 64x64 block changes
-__device__ __forceinline__ void lookup9(const GridView& g, const uint32_t (&c)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
-    uint32_t pblk = 0xFFFFFFFFu, poff = EMPTY;
+// Fine-table slots of the 3x3 cell box around (cx, cy), ascending.  The fine table is in global Morton order (blocks ranked in
+// Morton order, cells inside a block by the low 12 bits of their code), so sorting the SLOTS sorts the cells by Morton code —
+// no 32-bit codes, no de-interleaving of block coordinates.  Cells outside the u16 range or in blocks the directory does not
+// cover get EMPTY and sort to the end.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit positions.
+__device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2,4,6,8,10
+    v &= 63u;
+    v = (v | (v << 4)) & 0x30Fu;
+    v = (v | (v << 2)) & 0x333u;
+    v = (v | (v << 1)) & 0x555u;
+    return v;
+}
+__device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9]) {
+    uint32_t lx[3], ly[3], bx[3], by[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
+        lx[d] = spread6(x);
+        ly[d] = spread6(y) << 1;
+        // x = 65535 and the wrapped -1 are outside the reference's u16 cell range: an out-of-range block index makes them EMPTY
+        bx[d] = x < 65535u ? (x >> BLOCK_SHIFT) - g.bx0 : 0xFFFFFFFFu;
+        by[d] = y < 65535u ? (y >> BLOCK_SHIFT) - g.by0 : 0xFFFFFFFFu;
+    }
+    bool any = false;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            uint32_t off = EMPTY;
+            if (bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
+            any |= off != EMPTY;
+            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : off + (ly[dy] | lx[dx]);
+        }
+    sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
+    return any;
+}
+__device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const uint32_t blk = c[t] >> (2 * BLOCK_SHIFT);
-        if (blk != pblk) {
-            const uint32_t bx = compact1by1(blk) - g.bx0, by = compact1by1(blk >> 1) - g.by0;
-            poff = (bx < g.nbx && by < g.nby) ? gat(g.dir, by * g.nbx + bx) : EMPTY;
-            pblk = blk;
-        }
-        uint32_t a = 0, b = 0;
-        if (poff != EMPTY && c[t] != 0xFFFFFFFFu) {
-            const uint2 se = gat(g.fine, poff + (c[t] & (BLOCK_CELLS - 1u)));
-            a = se.x;
-            b = se.y;
-        }
-        s[t] = a;
-        e[t] = b;
+        uint2 se = make_uint2(0u, 0u);
+        if (slot[t] != EMPTY) se = gat(g.fine, slot[t]);
+        s[t] = se.x;
+        e[t] = se.y;
     }
 }
 
@@ -715,28 +738,12 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
         pi = lds_read_f2(&win[i - w0]);
         uint32_t cx, cy;
         cell_of(K, pi, cx, cy);
-        // Morton codes of the 3x3 box (3 + 3 bit spreads); cells outside the u16 range get the never-occupied code 0xFFFFFFFF
-        uint32_t px[3], py[3];
-        bool vx[3], vy[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
-            vx[d] = x < 65535u;
-            vy[d] = y < 65535u;
-            px[d] = part1by1(x);
-            py[d] = part1by1(y) << 1;
-        }
-        uint32_t c[9];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) c[dy * 3 + dx] = (vx[dx] && vy[dy]) ? (py[dy] | px[dx]) : 0xFFFFFFFFu;
-        sort9(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
         uint32_t flags = 0;
         uint32_t* const mytile = &tile[w][0][lane];
         // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
-        uint32_t s[9], e[9];
-        lookup9(gd, c, s, e);
+        uint32_t slot[9], s[9], e[9];
+        slots9(gd, cx, cy, slot);
+        ranges9(gd, slot, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // software pipeline: the next candidate's ds_read is in flight while the current one is tested.  The out-of-window
@@ -760,16 +767,10 @@ __global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict
             }
         }
         cd = ct;
-        // static neighbours: only waves that have a boundary block within one cell of some lane enter this section
-        bool near_static = false;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t bx = ((cx + ((q & 1) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.bx0;
-            const uint32_t by = ((cy + ((q & 2) ? 1u : 0xFFFFFFFFu)) >> BLOCK_SHIFT) - gs.by0;
-            if (bx < gs.nbx && by < gs.nby) near_static |= gat(gs.dir, by * gs.nbx + bx) != EMPTY;
-        }
+        // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
+        const bool near_static = slots9(gs, cx, cy, slot);
         if (__any(near_static)) {
-        lookup9(gs, c, s, e);
+        ranges9(gs, slot, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             for (uint32_t j = s[t]; j < e[t]; ++j) {
