@@ -1,0 +1,57 @@
+"""The headless C++ driver (yasph2d_amd/csrc/sphx_harness.cpp: world + TimeManager + Box<dyn Solver> of the host mirror, the
+non-drawing part of main.rs's loop) must end in exactly the state the Python-driven two-phase calls reach."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import yasph2d_amd as y
+
+pytestmark = pytest.mark.gpu
+
+HARNESS = os.path.join(os.path.dirname(os.path.abspath(y.__file__)), "sphx_harness")
+
+
+def fnv1a(data):
+    h = 1469598103934665603
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("solver,extra", [("dfsph", []), ("dfsph", ["--no-law"]), ("wcsph", [])])
+def test_harness_matches_python_driver(solver, extra):
+    steps = 120
+    out = subprocess.run([HARNESS, "--solver", solver, "--scale", "1", "--steps", str(steps), "--warmup", "0"] + extra, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    w = y.FluidParticleWorld()
+    w.reset_fluid(1.0)
+    ctx = y.SphxContext()
+    ctx.set_boundary(w.boundary_particles)
+    ctx.upload(w.positions)
+    timer = y.TimeManager(cfl_factor=0.2) if solver == "wcsph" else y.TimeManager()
+    diam = np.float32(0.01)
+    for _ in range(steps):
+        if solver == "wcsph":
+            vmax = ctx.wcsph_step_begin(timer.simulation_step())
+            ctx.wcsph_step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+        else:
+            vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+            ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+    d = ctx.download()
+    by_id = np.zeros((len(d["ids"]), 4), np.float32)
+    by_id[d["ids"], :2] = d["pos"]
+    by_id[d["ids"], 2:] = d["vel"]
+    assert res["particles"] == len(d["ids"]) and res["steps"] == steps
+    assert res["timer_step_ns"] == timer.simulation_step_ns()
+    assert int(res["state_fnv1a"], 16) == fnv1a(by_id.tobytes())
+    assert res["particle_steps_per_s"] > 0
+
+
+def test_harness_rejects_unknown_arguments():
+    out = subprocess.run([HARNESS, "--bogus"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2
