@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # Exactly ONE line on stdout: RCCL prints a version banner and gloo its connection notes to fd 1, from C code.  Everything
+    # written to fd 1 during the run goes to stderr; the result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +94,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev
-    if world > 1:
+    if world > 1 or (args.force_tiles and "RANK" in os.environ):  # world 1 under torchrun + --force-tiles: exercises the collectives alone
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -256,7 +262,8 @@ def main():
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1 and args.solver == "dfsph":
             out["cpu_baseline"] = cpu_baseline(pos, boundary)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
