@@ -214,6 +214,9 @@ void sphx_shm_close(sphx_shm* h);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 int sphx_synchronize(sphx_ctx* ctx);
+/* Run this context on a HIP stream owned by the caller (hipStream_t; NULL = back to a private stream).  The tile driver passes
+ * the stream RCCL orders its sends/receives against, so packing, exchange and unpacking need no host synchronisation. */
+int sphx_set_stream(sphx_ctx* ctx, void* hip_stream);
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream; totals are kept per kernel name. */
 int sphx_profile_enable(sphx_ctx* ctx, int on);
 int sphx_profile_reset(sphx_ctx* ctx);

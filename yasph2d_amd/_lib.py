@@ -121,6 +121,7 @@ SIGNATURES = {
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
     "sphx_shm_close": (None, [_vp]),
     "sphx_synchronize": (_i, [_vp]),
+    "sphx_set_stream": (_i, [_vp, _vp]),
     "sphx_profile_enable": (_i, [_vp, _i]),
     "sphx_profile_reset": (_i, [_vp]),
     "sphx_profile_get": (_i, [_vp, _vp, C.POINTER(_u32)]),

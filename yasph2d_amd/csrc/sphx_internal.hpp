@@ -168,6 +168,7 @@ struct sphx_ctx {
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
+    bool external_stream = false;  // c->stream belongs to the caller (sphx_set_stream)
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;

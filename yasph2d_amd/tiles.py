@@ -18,6 +18,7 @@ The driver is backend-agnostic: `GpuTileBackend` (libsphx, the product) or the o
 (tests/tile_oracle_backend.py) implement the same sub-step interface, and `TorchComm` runs over RCCL ("nccl") on GPUs and
 over gloo in the CPU tests.
 """
+import contextlib
 import ctypes as C
 import threading
 
@@ -84,7 +85,9 @@ class TorchComm:
         self.dist, self.device = dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def exchange(self, send_left, send_right, recv_left, recv_right):
+    def exchange(self, send_left, send_right, recv_left, recv_right, stream_ordered=False):
+        """stream_ordered: the caller's kernels run on torch's CURRENT stream (GpuTileBackend.stream_context), so the collective
+        library's stream semantics order pack -> send/recv -> unpack and no host synchronisation is needed."""
         import torch
         import torch.distributed as dist
 
@@ -106,7 +109,7 @@ class TorchComm:
                     recv_left.copy_(rl)
                 if self.rank < self.world - 1:
                     recv_right.copy_(rr)
-            if send_left.is_cuda:
+            if send_left.is_cuda and not stream_ordered:
                 torch.cuda.synchronize(send_left.device)
 
     def _red_device(self):
@@ -180,7 +183,11 @@ class ThreadComm:
     def __init__(self, shared, rank):
         self.sh, self.rank, self.world = shared, rank, shared.world
 
-    def exchange(self, send_left, send_right, recv_left, recv_right):
+    def exchange(self, send_left, send_right, recv_left, recv_right, stream_ordered=False):
+        if send_left.is_cuda:
+            import torch
+
+            torch.cuda.synchronize()  # the other thread reads these buffers from its own stream
         self.sh.slots[self.rank]["L"], self.sh.slots[self.rank]["R"] = send_left, send_right
         self.sh.barrier.wait()
         if self.rank > 0:
@@ -212,13 +219,24 @@ class ThreadComm:
 class GpuTileBackend:
     """The product path: one libsphx context per tile; halo buffers are torch device tensors handed to RCCL as they are."""
 
-    def __init__(self, ctx, device=None):
+    def __init__(self, ctx, device=None, own_stream=True):
         import torch
 
         self.ctx = ctx
         self.L = ctx.L
         self.torch = torch
         self.device = device if device is not None else torch.device("cuda", ctx.params.device)
+        # One torch stream carries the context's kernels AND the communication library's view of "current stream": packing,
+        # RCCL send/recv and unpacking are ordered by the stream, the host never blocks in an exchange.
+        self.stream = None
+        if own_stream:
+            self.stream = torch.cuda.Stream(self.device)
+            self._chk(self.L.sphx_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+
+    def stream_context(self):
+        import contextlib
+
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _chk(self, rc):
         if rc:
@@ -226,7 +244,10 @@ class GpuTileBackend:
 
     def make_buffers(self, cap):
         n = (1 + cap) * HALO_RECORD_BYTES
-        return [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(4)]
+        with self.stream_context():
+            bufs = [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(4)]
+        self.torch.cuda.synchronize(self.device)
+        return bufs
 
     def set_boundary(self, xy):
         self.ctx.set_boundary(xy)
@@ -377,7 +398,9 @@ class TiledDFSPH:
         """Halo exchange (migration + fresh ghosts) followed by the re-grid of the local set."""
         sl, sr, rl, rr = self.bufs
         self.b.pack(sl, sr, self.cap)
-        self.comm.exchange(sl, sr, rl, rr)
+        ordered = getattr(self.b, "stream", None) is not None  # kernels and communication share one stream: no host sync
+        with (self.b.stream_context() if ordered else contextlib.nullcontext()):
+            self.comm.exchange(sl, sr, rl, rr, stream_ordered=ordered)
         self.b.apply(rl if self.has_left else None, rr if self.has_right else None, self.cap)
         self.n_local = self.b.regrid()
         self.exchanges += 1
