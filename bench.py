@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
+    ap.add_argument("--tiles", default="auto", choices=["auto", "strips", "grid"],
+                    help="multi-GPU layout: strips along the longer side, or a 2 x N/2 grid (auto: 2x2 on 4 GPUs, strips otherwise; SURVEY 8(e))")
     ap.add_argument("--rebalance-every", type=int, default=16, help="steps between re-partitions of the tile cuts (0 = never)")
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
@@ -139,12 +141,19 @@ def main():
 
         tiled = None
     else:
-        from yasph2d_amd.tiles import GpuTileBackend, ShmComm, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+        from yasph2d_amd.tiles import GpuTileBackend, GridLayout, ShmComm, StripLayout, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
 
-        # strips across the longer side of the fluid, cut at particle-count quantiles (equal particles per GPU)
+        # cut at particle-count quantiles (equal particles per GPU): strips across the longer side of the fluid, or columns cut again
         ext = pos.max(0) - pos.min(0)
         axis = int(ext[1] > ext[0])
-        cuts = quantile_cuts(cell_coord(pos, axis), world)
+        grid = args.tiles == "grid" or (args.tiles == "auto" and world == 4)
+        if grid and world % 2 == 0 and world >= 4:
+            nx, ny = (2, world // 2) if axis == 1 else (world // 2, 2)
+            layout = GridLayout.quantile(pos, nx, ny)
+            layout_name = f"{nx}x{ny} tiles (columns cut at particle-count quantiles, each column cut again across)"
+        else:
+            layout = StripLayout(axis, quantile_cuts(cell_coord(pos, axis), world))
+            layout_name = f"{world} spatial strips along {'xy'[axis]} cut at particle-count quantiles"
         if dist is not None:
             if args.scalar_comm == "shm":
                 comm = ShmComm(dist, torch.device("cuda", dev_index), "bench" + os.environ.get("MASTER_PORT", "0"))
@@ -154,7 +163,7 @@ def main():
             from yasph2d_amd.tiles import ThreadComm
 
             comm = ThreadComm(ThreadComm.Shared(1), 0)
-        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, axis, cuts, halo=args.halo,
+        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, layout, halo=args.halo,
                            rebalance_every=args.rebalance_every)
         tiled.setup(pos, None, None, boundary)
         n = n_global // world
@@ -248,8 +257,8 @@ def main():
                 "particles_per_gpu": n,
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
-                f"{world} spatial strips along {'xy'[tiled.axis]} cut at particle-count quantiles, {args.halo}-cell ghost halo, per step: 1 halo "
-                f"exchange (send/recv with <= 2 neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
+                f"{layout_name}, {args.halo}-cell ghost halo, per step: 1 halo "
+                f"exchange (send/recv with {len(tiled.peers)} neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
                 f"{tiled.rebalances} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
             },

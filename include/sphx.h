@@ -190,6 +190,14 @@ int sphx_get_constants(const sphx_ctx* ctx, float* out6);
  * In tile mode the warm-start arrays travel with their particle (a slot-bound array has no meaning across tiles). */
 int sphx_reserve(sphx_ctx* ctx, uint32_t capacity); /* device capacity in particles (owned + ghosts + 2 halo buffers); before upload */
 int sphx_tile_configure(sphx_ctx* ctx, int axis, uint32_t cell_lo, uint32_t cell_hi, uint32_t halo_cells, int has_left, int has_right);
+/* General form ("4 GPUs: 2x2 tiles"): the context owns the cell rectangle *own; peers[] are the rectangles of the
+ * tiles that touch it by an edge or a corner (<= SPHX_MAX_TILE_PEERS), in the order of the buffers given to sphx_tile_pack_n /
+ * sphx_tile_apply_n.  A strip is a rectangle spanning the whole other axis; sphx_tile_configure/pack/apply are that special case. */
+#define SPHX_MAX_TILE_PEERS 8
+typedef struct sphx_tile_rect { uint32_t x0, x1, y0, y1; } sphx_tile_rect; /* cells, half-open */
+int sphx_tile_configure_rect(sphx_ctx* ctx, const sphx_tile_rect* own, uint32_t halo_cells, const sphx_tile_rect* peers, uint32_t n_peers);
+int sphx_tile_pack_n(sphx_ctx* ctx, void* const* d_send, uint32_t n_send, uint32_t cap_records);         /* n_send == n_peers */
+int sphx_tile_apply_n(sphx_ctx* ctx, const void* const* d_recv, uint32_t n_recv, uint32_t cap_records);  /* entries may be NULL */
 int sphx_tile_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, const uint32_t* ids, uint32_t n); /* owned particles, global ids < 2^31 */
 #define SPHX_HALO_RECORD_BYTES 32 /* {float4 pos+vel, u32 id, f32 kappa, f32 stiffness, u32 pad}; record 0 = header (count in .id) */
 int sphx_tile_pack(sphx_ctx* ctx, void* d_send_left, void* d_send_right, uint32_t cap_records);              /* DEVICE buffers, (1+cap)*32 B */

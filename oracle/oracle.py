@@ -114,6 +114,7 @@ def lib(omp=False):
         "orc_get_neighbor_lists": (None, [vp, vp]),
         "orc_get_neighbor_flags": (u32, [vp]),
         "orc_tile_configure": (None, [vp, i32, u32, u32]),
+        "orc_tile_configure_rect": (None, [vp, u32, u32, u32, u32]),
         "orc_tile_set_state": (None, [vp, vp, vp, vp, vp, vp, u32]),
         "orc_sub_regrid": (None, [vp]),
         "orc_sub_nonpressure": (f32, [vp, f32]),

@@ -1058,8 +1058,7 @@ struct WCSPHSolver {  // wscsph.rs:14-23
 // C API (ctypes)
 // =====================================================================================
 struct OrcTile {  // spatial-tile test support (see the sub-step API at the end of this file)
-    int axis = 0;
-    uint32_t lo = 0, hi = 65536;
+    uint32_t x0 = 0, x1 = 65536, y0 = 0, y1 = 65536;  // owned cell rectangle, half-open
     std::vector<V2> accel;
 };
 struct OrcSim {
@@ -1312,14 +1311,20 @@ uint32_t orc_get_neighbor_flags(OrcSim* s) { return s->world.neighborhood.neighb
 static inline bool tile_owns(OrcSim* s, const OrcTile& t, V2 p) {  // C linkage is fine for a static helper
     uint16_t cx, cy;
     s->world.neighborhood.grid.position_to_cell(p, cx, cy);
-    const uint32_t c = t.axis ? cy : cx;
-    return c >= t.lo && c < t.hi;
+    return cx >= t.x0 && cx < t.x1 && cy >= t.y0 && cy < t.y1;
 }
-void orc_tile_configure(OrcSim* s, int axis, uint32_t lo, uint32_t hi) {
+void orc_tile_configure_rect(OrcSim* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
     OrcTile& t = s->tile;
-    t.axis = axis;
-    t.lo = lo;
-    t.hi = hi;
+    t.x0 = x0;
+    t.x1 = x1;
+    t.y0 = y0;
+    t.y1 = y1;
+}
+void orc_tile_configure(OrcSim* s, int axis, uint32_t lo, uint32_t hi) {  // a strip: the whole other axis
+    if (axis)
+        orc_tile_configure_rect(s, 0, 65536, lo, hi);
+    else
+        orc_tile_configure_rect(s, lo, hi, 0, 65536);
 }
 void orc_tile_set_state(OrcSim* s, const float* pos, const float* vel, const uint32_t* ids, const float* kappa, const float* stiff, uint32_t n) {
     World& w = s->world;

@@ -73,3 +73,24 @@ def test_gpu_tiles_rebalance_bit_exact_vs_oracle_tiles():
         np.testing.assert_array_equal(g[r][0]["ids"], o[r][0]["ids"])
         for k in ("pos", "vel", "density", "kappa", "stiffness"):
             assert_bits_equal(g[r][0][k], o[r][0][k], f"rank {r} {k}")
+
+
+def test_gpu_tiles_2x2_bit_exact_vs_oracle_tiles():
+    """SURVEY.md 8(e) "4 GPUs: 2x2 tiles": four tile threads on one MI355X (three peers each: two edges and a corner), fixed 3+2
+    iterations through the impact (warm starts, diagonal migration, budget-triggered extra exchanges), cuts re-partitioned every
+    4 steps: the HIP tiles follow the oracle tiles bit for bit."""
+    from test_tiles_cpu import GridLayout
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(2.0)
+    kw = dict(halo=10, fixed=(3, 2), rebalance_every=4, layout=lambda: GridLayout.quantile(pos, 2, 2))
+    g, _ = run_tiles_threaded(gpu_backend, pos, boundary, 4, None, 150, **kw)
+    gl = list(run_tiles_threaded.final_cuts)
+    o, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 4, None, 150, **kw)
+    assert gl == list(run_tiles_threaded.final_cuts) and gl[0][1] > 3
+    merge_owned(g, len(pos))  # every particle owned exactly once
+    for r in range(4):
+        assert g[r][2] == o[r][2]  # same number of halo exchanges
+        np.testing.assert_array_equal(g[r][0]["ids"], o[r][0]["ids"])
+        for k in ("pos", "vel", "density", "kappa", "stiffness"):
+            assert_bits_equal(g[r][0][k], o[r][0][k], f"rank {r} {k}")

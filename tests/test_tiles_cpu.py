@@ -11,7 +11,7 @@ from util import dam_break
 
 import yasph2d_amd as y
 from oracle.oracle import Oracle
-from yasph2d_amd.tiles import ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
+from yasph2d_amd.tiles import GridLayout, StripLayout, ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,15 +27,17 @@ def single_domain(pos, boundary, steps, fixed=(0, 0)):
     return dict(pos=o.positions()[inv], vel=o.velocities()[inv], density=o.densities()[inv]), stats, o.timer_step_ns()
 
 
-def run_tiles_threaded(make_backend, pos, boundary, world, axis, steps, halo=16, fixed=(0, 0), cuts=None, rebalance_every=0):
-    cuts = quantile_cuts(cell_coord(pos, axis), world) if cuts is None else cuts
+def run_tiles_threaded(make_backend, pos, boundary, world, axis, steps, halo=16, fixed=(0, 0), cuts=None, rebalance_every=0, layout=None):
+    """axis/cuts: strips; layout: a factory returning a fresh Layout per rank (e.g. a 2x2 GridLayout)."""
+    cuts = quantile_cuts(cell_coord(pos, axis), world) if cuts is None and layout is None else cuts
     shared = ThreadComm.Shared(world)
     out, errs = [None] * world, []
     final_cuts = run_tiles_threaded.final_cuts = [None] * world
 
     def work(r):
         try:
-            t = TiledDFSPH(make_backend(r), ThreadComm(shared, r), axis, cuts, halo=halo, fixed_iterations=fixed, rebalance_every=rebalance_every)
+            lay = layout() if layout is not None else StripLayout(axis, cuts)
+            t = TiledDFSPH(make_backend(r), ThreadComm(shared, r), lay, halo=halo, fixed_iterations=fixed, rebalance_every=rebalance_every)
             t.setup(pos, None, None, boundary)
             timer = y.TimeManager()
             stats = [t.step(timer) for _ in range(steps)]
@@ -145,6 +147,74 @@ def test_tiles_rebalance_moves_cuts_and_matches_single_domain():
     np.testing.assert_allclose(p, ref["pos"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v, ref["vel"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(d, ref["density"], rtol=1e-5)
+
+
+def test_grid_layout_geometry():
+    from yasph2d_amd.tiles import in_rect, rects_touch
+
+    pos, _ = dam_break(2.0)
+    lay = GridLayout.quantile(pos, 2, 2)
+    rects = lay.rects()
+    assert len(rects) == 4 and rects[0][0] == 0 and rects[3][1] == 65536 and rects[0][2] == 0 and rects[1][3] == 65536
+    cx, cy = cell_coord(pos, 0), cell_coord(pos, 1)
+    owner = sum(in_rect(cx, cy, r).astype(int) for r in rects)
+    assert (owner == 1).all(), "the rectangles partition the domain"
+    counts = [int(in_rect(cx, cy, r).sum()) for r in rects]
+    assert max(counts) < 1.1 * min(counts), "quantile cuts balance the tiles"
+    for a in range(4):
+        assert sum(rects_touch(rects[a], rects[b], 8) for b in range(4) if b != a) == 3  # edge + corner neighbours
+
+
+def test_tiles_2x2_match_single_domain():
+    """SURVEY.md 8(e) "4 GPUs: 2x2 tiles": columns cut again across, every tile has two edge neighbours and a corner neighbour;
+    particles migrate across both cuts and diagonally.  Same bar as the strips."""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(2.0)
+    steps = 60
+    ref, rstats, _ = single_domain(pos, boundary, steps)
+    outs, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 4, None, steps, halo=8, layout=lambda: GridLayout.quantile(pos, 2, 2))
+    for s in range(steps):
+        for r in range(4):
+            st = outs[r][1][s]
+            assert st["density_iterations"] == rstats[s]["density_iterations"] and st["divergence_iterations"] == rstats[s]["divergence_iterations"]
+            assert np.float32(st["dt"]) == np.float32(rstats[s]["dt"]) and np.float32(st["vmax"]) == np.float32(rstats[s]["vmax"])
+    p, v, d = merge_owned(outs, len(pos))
+    np.testing.assert_allclose(p, ref["pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v, ref["vel"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d, ref["density"], rtol=1e-5)
+
+
+def test_tiles_2x2_impact_migration_rebalance():
+    """Fixed 3+2 iterations (warm starts, budget-triggered extra exchanges) into the impact with the cuts re-partitioned every
+    4 steps, 2x2 tiles vs ONE tile of the same code path.  (The order inside a cell differs between tilings once particles have
+    crossed an x-cut; the impact amplifies that round-off chaotically — by step 150 to 1e-5 in position for x-strips and 2x2 tiles
+    alike — so the comparison stops at step 100.)"""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(2.0)
+    steps = 100
+    one, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 1, 1, steps, fixed=(3, 2))
+    four, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 4, None, steps, fixed=(3, 2), halo=10, rebalance_every=4,
+                                 layout=lambda: GridLayout.quantile(pos, 2, 2))
+    states = run_tiles_threaded.final_cuts
+    assert all(st == states[0] for st in states) and states[0][1] > 3, "all ranks hold the same, re-partitioned layout"
+    p1, v1, _ = merge_owned(one, len(pos))
+    p4, v4, _ = merge_owned(four, len(pos))
+    np.testing.assert_allclose(p4, p1, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v4, v1, rtol=1e-4, atol=1e-3)
+    lay = GridLayout.quantile(pos, 2, 2)
+    own0 = np.array([[in_rect_one(pos[i], r) for r in lay.rects()].index(True) for i in range(0, len(pos), 7)])
+    lay2 = GridLayout(states[0][0][0], states[0][0][1:])
+    own1 = np.array([[in_rect_one(p4[i], r) for r in lay2.rects()].index(True) for i in range(0, len(pos), 7)])
+    assert (own0 != own1).sum() > 0, "particles changed owner"
+
+
+def in_rect_one(p, rect):
+    from yasph2d_amd.tiles import in_rect
+
+    q = np.asarray(p, np.float32).reshape(1, 2)
+    return bool(in_rect(cell_coord(q, 0), cell_coord(q, 1), rect)[0])
 
 
 GLOO_WORKER = r'''

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle.oracle import Oracle
-from yasph2d_amd.tiles import HALO_DTYPE, HALO_RECORD_BYTES, cell_coord
+from yasph2d_amd.tiles import HALO_DTYPE, HALO_RECORD_BYTES, cell_coord, in_rect
 
 OWNED = np.uint32(0x80000000)
 
@@ -20,15 +20,15 @@ class OracleTileBackend:
         self.o = Oracle()
         self.L = self.o.L
 
-    def make_buffers(self, cap):
-        return [torch.zeros((1 + cap) * HALO_RECORD_BYTES, dtype=torch.uint8) for _ in range(4)]
+    def make_buffers(self, cap, count):
+        return [torch.zeros((1 + cap) * HALO_RECORD_BYTES, dtype=torch.uint8) for _ in range(count)]
 
     def set_boundary(self, xy):
         self.o.set_boundary(xy)
 
-    def configure(self, axis, lo, hi, halo, has_left, has_right):
-        self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right = axis, lo, hi, halo, has_left, has_right
-        self.L.orc_tile_configure(self.o.h, axis, lo, hi)
+    def configure(self, own, halo, peer_rects):
+        self.rect, self.halo, self.peer_rects = tuple(own), halo, [tuple(r) for r in peer_rects]
+        self.L.orc_tile_configure_rect(self.o.h, *self.rect)
 
     def reserve(self, capacity):
         pass
@@ -44,20 +44,22 @@ class OracleTileBackend:
         return self.o.positions(), self.o.velocities(), self.o.ids(), (self.o.kappa() if n else np.zeros(0, np.float32)), (
             self.o.stiffness() if n else np.zeros(0, np.float32))
 
+    def _cells(self, pos):
+        return cell_coord(pos, 0), cell_coord(pos, 1)
+
     def upload(self, pos, vel, ids):
         n = len(pos)
         self._set(pos, vel, np.asarray(ids, np.uint32) | OWNED, np.zeros(n, np.float32), np.zeros(n, np.float32))
 
-    def pack(self, send_left, send_right, cap):
+    def pack(self, sends, cap):
+        """k_tile_count/offsets/pack: for every peer the owned particles inside its rectangle grown by the halo, ascending index."""
         pos, vel, ids, kappa, stiff = self._state()
-        owned = (ids >> np.uint32(31)) != 0
-        c = cell_coord(pos, self.axis)
-        for buf, has, sel in ((send_left, self.has_left, owned & (c < self.lo + self.halo)), (send_right, self.has_right, owned & (c + self.halo >= self.hi))):
+        owned = ((ids >> np.uint32(31)) != 0) & ~np.isnan(pos[:, 0]) if len(pos) else np.zeros(0, bool)
+        cx, cy = self._cells(pos)
+        for buf, rect in zip(sends, self.peer_rects):
             rec = buf.numpy().view(HALO_DTYPE)
             rec[:] = 0
-            if not has:
-                continue
-            idx = np.nonzero(sel)[0]
+            idx = np.nonzero(owned & in_rect(cx, cy, rect, self.halo))[0]
             assert len(idx) <= cap, "halo buffer too small"
             rec["id"][0] = len(idx)
             r = rec[1:1 + len(idx)]
@@ -67,27 +69,24 @@ class OracleTileBackend:
             r["kappa"] = kappa[idx]
             r["stiff"] = stiff[idx]
 
-    def apply(self, recv_left, recv_right, cap):
+    def apply(self, recvs, cap):
         pos, vel, ids, kappa, stiff = self._state()
         owned = (ids >> np.uint32(31)) != 0
-        c = cell_coord(pos, self.axis)
-        own = owned & (c >= self.lo) & (c < self.hi)
-        # owned particles that crossed a cut stay as ghosts while they are inside the ghost band (k_tile_drop)
-        keep = own | (owned & (c + self.halo >= self.lo) & (c < self.hi + self.halo))
+        cx, cy = self._cells(pos)
+        own = owned & in_rect(cx, cy, self.rect)
+        # owned particles that crossed a cut stay as ghosts while they are inside the ghost band (k_tile_pack's retire rule)
+        keep = own | (owned & in_rect(cx, cy, self.rect, self.halo))
         ids = np.where(own, ids, ids & np.uint32(0x7FFFFFFF)).astype(np.uint32)
         parts = [(pos[keep], vel[keep], ids[keep], kappa[keep], stiff[keep])]
-        for buf in (recv_left, recv_right):
-            if buf is None:
-                continue
+        for buf in recvs:
             rec = buf.numpy().view(HALO_DTYPE)
             cnt = int(rec["id"][0])
             r = rec[1:1 + cnt]
             p, v = r["pv"][:, :2].copy(), r["pv"][:, 2:].copy()
-            cc = cell_coord(p, self.axis)
-            own = (cc >= self.lo) & (cc < self.hi)
-            ghost = (cc + self.halo >= self.lo) & (cc < self.hi + self.halo)
-            m = own | ghost
-            parts.append((p[m], v[m], (r["id"] | np.where(own, OWNED, np.uint32(0)).astype(np.uint32))[m], r["kappa"][m], r["stiff"][m]))
+            ccx, ccy = self._cells(p)
+            o = in_rect(ccx, ccy, self.rect)
+            m = in_rect(ccx, ccy, self.rect, self.halo)
+            parts.append((p[m], v[m], (r["id"] | np.where(o, OWNED, np.uint32(0)).astype(np.uint32))[m], r["kappa"][m], r["stiff"][m]))
         self._set(*[np.concatenate([q[k] for q in parts]) for k in range(5)])
 
     def regrid(self):

@@ -120,6 +120,9 @@ SIGNATURES = {
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
     "sphx_shm_close": (None, [_vp]),
+    "sphx_tile_configure_rect": (_i, [_vp, _vp, _u32, _vp, _u32]),
+    "sphx_tile_pack_n": (_i, [_vp, _vp, _u32, _u32]),
+    "sphx_tile_apply_n": (_i, [_vp, _vp, _u32, _u32]),
     "sphx_synchronize": (_i, [_vp]),
     "sphx_set_stream": (_i, [_vp, _vp]),
     "sphx_profile_enable": (_i, [_vp, _i]),

@@ -27,6 +27,11 @@ constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2:
 enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
+constexpr uint32_t MAX_TILE_PEERS = 8;  // a rectangle has at most 8 neighbours (4 edges + 4 corners) in a regular tiling
+struct TileRect {
+    uint32_t x0, x1, y0, y1;  // cells, half-open
+};
+
 struct Consts {
     float h;         // smoothing length = search radius = cell size
     float radius_sq; // grid.radius * grid.radius (neighborhood_search.rs:331)
@@ -39,9 +44,9 @@ struct Consts {
     float ax, ay;    // non_pressure_accelleration = gravity*m/m (dfsph.rs:442-444)
     float gx, gy;    // gravity itself (wscsph.rs:83)
     float wc_stiffness, wc_boundary_force;  // WCSPHSolver::set_compressibility(.., 0.01, 1.0), boundary_force_factor (wscsph.rs:31-49)
-    // spatial tile owned by this context (multi-GPU): cells with tile_lo <= c < tile_hi along tile_axis; reductions only count
-    // owned particles.  Single-GPU default: [0, 65536).
-    uint32_t tile_axis, tile_lo, tile_hi;
+    // spatial tile owned by this context (multi-GPU): the cell rectangle [x0,x1) x [y0,y1); reductions only count owned
+    // particles.  Single-GPU default: the whole domain.
+    TileRect tile;
     // a wave whose lanes' candidate index spans all stay <= span_limit stores 16-bit list entries (65536; 0 forces 32-bit lists)
     uint32_t span_limit;
 };
@@ -187,9 +192,11 @@ struct sphx_ctx {
     // tile mode (multi-GPU spatial decomposition)
     bool tile_mode = false;
     uint32_t tile_halo = 0;
-    int tile_has_left = 0, tile_has_right = 0;
+    uint32_t tile_npeers = 0;
+    sphx::TileRect tile_peer[sphx::MAX_TILE_PEERS] = {};
     uint32_t n_owned = 0;
-    uint2 *tile_scan_l = nullptr, *tile_scan_r = nullptr;  // [capN] send-set compaction scratch
+    uint32_t* tile_blk = nullptr;  // per-workgroup send counts / offsets, MAX_TILE_PEERS per workgroup
+    bool tile_strip_left = false, tile_strip_right = false;  // strip form of the configuration (sphx_tile_configure)
 
     // profiling
     bool profiling = false;

@@ -33,13 +33,15 @@ __device__ __forceinline__ void cell_of(const Consts& K, float2 p, uint32_t& cx,
     cy = sat_u16((p.y - K.gmin_y) * K.cell_inv);
 }
 
-// multi-GPU tiles: a particle is OWNED by this context iff its cell coordinate along the tile axis is in [tile_lo, tile_hi)
-__device__ __forceinline__ uint32_t tile_coord(const Consts& K, float px, float py) {
-    return K.tile_axis ? sat_u16((py - K.gmin_y) * K.cell_inv) : sat_u16((px - K.gmin_x) * K.cell_inv);
+// multi-GPU tiles: a particle is OWNED by this context iff its cell lies in the context's rectangle [x0,x1) x [y0,y1)
+// (a strip = a rectangle that spans the whole other axis)
+__device__ __forceinline__ bool rect_has(const TileRect& r, uint32_t cx, uint32_t cy, uint32_t halo) {
+    return cx + halo >= r.x0 && cx < r.x1 + halo && cy + halo >= r.y0 && cy < r.y1 + halo;
 }
 __device__ __forceinline__ bool tile_owns(const Consts& K, float px, float py) {
-    const uint32_t c = tile_coord(K, px, py);
-    return c >= K.tile_lo && c < K.tile_hi;
+    uint32_t cx, cy;
+    cell_of(K, make_float2(px, py), cx, cy);
+    return rect_has(K.tile, cx, cy, 0u);
 }
 
 __device__ __forceinline__ uint32_t compact1by1(uint32_t x) {  // morton.rs:57-65
@@ -466,68 +468,68 @@ struct HaloRec {
     uint32_t pad;
 };
 // ---- halo pack: 3 launches -------------------------------------------------------------------------------------------------
-// Send sets: owned particles within `halo` cells of the left / right cut (particles that migrated across it included), in
-// ascending local index — the receiver's stable sort turns arrival order into the order inside a cell, so it must be
-// deterministic.  k_tile_count: per-workgroup counts; k_tile_offsets: one workgroup scans them and writes both headers;
-// k_tile_pack: recomputes the flags, ranks inside the workgroup with ballots, writes the records — and retires what this
-// tile no longer owns.
-__device__ __forceinline__ void tile_send_flags(const Consts& K, uint32_t halo, float4 pv, uint32_t id, bool has_l, bool has_r, bool& fl, bool& fr) {
+// Send set for neighbour k: the owned particles inside k's rectangle grown by `halo` cells (particles that migrated into it
+// included), in ascending local index — the receiver's stable sort turns arrival order into the order inside a cell, so it must
+// be deterministic.  k_tile_count: per-workgroup counts per neighbour; k_tile_offsets: one workgroup scans them and writes the
+// headers; k_tile_pack: recomputes the flags, ranks inside the workgroup with ballots, writes the records — and retires what this
+// tile no longer holds.
+struct TilePeers {
+    uint32_t n;                  // number of neighbouring tiles (<= MAX_TILE_PEERS)
+    TileRect rect[MAX_TILE_PEERS];
+    HaloRec* out[MAX_TILE_PEERS];  // send buffers: record 0 = header (count), then the records
+};
+__device__ __forceinline__ uint32_t tile_send_mask(const Consts& K, const TilePeers& P, uint32_t halo, float4 pv, uint32_t id) {
     const bool owned = (id >> 31) != 0 && pv.x == pv.x;
-    const uint32_t c = tile_coord(K, pv.x, pv.y);
-    fl = has_l && owned && c < K.tile_lo + halo;
-    fr = has_r && owned && c + halo >= K.tile_hi;
+    if (!owned) return 0u;
+    uint32_t cx, cy;
+    cell_of(K, make_float2(pv.x, pv.y), cx, cy);
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < P.n; ++k) m |= rect_has(P.rect[k], cx, cy, halo) ? (1u << k) : 0u;
+    return m;
 }
 __global__ __launch_bounds__(256) void k_tile_count(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
-                                                     uint32_t halo, uint32_t has_l, uint32_t has_r, uint2* __restrict__ blk) {
-    __shared__ uint32_t wl[4], wr[4];
+                                                     uint32_t halo, TilePeers P, uint32_t* __restrict__ blk) {
+    __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    bool fl = false, fr = false;
-    if (i < n) tile_send_flags(K, halo, PV[i], pid[i], has_l != 0, has_r != 0, fl, fr);
-    const uint32_t cl = (uint32_t)__popcll(__ballot(fl)), cr = (uint32_t)__popcll(__ballot(fr));
-    if ((threadIdx.x & 63) == 0) {
-        wl[threadIdx.x >> 6] = cl;
-        wr[threadIdx.x >> 6] = cr;
+    const uint32_t m = i < n ? tile_send_mask(K, P, halo, PV[i], pid[i]) : 0u;
+    for (uint32_t k = 0; k < P.n; ++k) {
+        const uint32_t c = (uint32_t)__popcll(__ballot((m >> k) & 1u));
+        if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6][k] = c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(wl[0] + wl[1] + wl[2] + wl[3], wr[0] + wr[1] + wr[2] + wr[3]);
+    if (threadIdx.x < P.n) blk[(size_t)blockIdx.x * MAX_TILE_PEERS + threadIdx.x] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
 }
-// exclusive scan of the per-workgroup counts in place (one workgroup of 1024); totals -> record 0 of each send buffer
-__global__ __launch_bounds__(1024) void k_tile_offsets(uint2* __restrict__ blk, uint32_t nb, HaloRec* __restrict__ out_l, HaloRec* __restrict__ out_r) {
-    __shared__ uint2 part[1024];
+// exclusive scan of the per-workgroup counts in place (one workgroup of 1024, one neighbour after the other); totals -> record 0
+__global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ blk, uint32_t nb, TilePeers P) {
+    __shared__ uint32_t part[1024];
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
-    uint2 acc = make_uint2(0, 0);
-    for (uint32_t b = b0; b < b1; ++b) {
-        const uint2 v = blk[b];
-        acc.x += v.x;
-        acc.y += v.y;
-    }
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint2 v = make_uint2(0, 0);
-        if (threadIdx.x >= off) v = part[threadIdx.x - off];
+    for (uint32_t k = 0; k < P.n; ++k) {
+        uint32_t acc = 0;
+        for (uint32_t b = b0; b < b1; ++b) acc += blk[(size_t)b * MAX_TILE_PEERS + k];
+        part[threadIdx.x] = acc;
         __syncthreads();
-        part[threadIdx.x].x += v.x;
-        part[threadIdx.x].y += v.y;
+        for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t v = blk[(size_t)b * MAX_TILE_PEERS + k];
+            blk[(size_t)b * MAX_TILE_PEERS + k] = run;
+            run += v;
+        }
+        if (threadIdx.x == 1023) {
+            HaloRec h;
+            h.pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            h.kappa = h.stiff = 0.0f;
+            h.pad = 0;
+            h.id = part[1023];
+            P.out[k][0] = h;
+        }
         __syncthreads();
-    }
-    uint2 run = threadIdx.x ? part[threadIdx.x - 1] : make_uint2(0, 0);
-    for (uint32_t b = b0; b < b1; ++b) {
-        const uint2 v = blk[b];
-        blk[b] = run;
-        run.x += v.x;
-        run.y += v.y;
-    }
-    if (threadIdx.x == 1023) {
-        HaloRec h;
-        h.pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        h.kappa = h.stiff = 0.0f;
-        h.pad = 0;
-        h.id = part[1023].x;
-        out_l[0] = h;
-        h.id = part[1023].y;
-        out_r[0] = h;
     }
 }
 // Records out; then: ghosts of the previous step vanish at the next re-grid (a NaN position gets no cell), and so do owned
@@ -535,28 +537,26 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint2* __restrict__ blk, 
 // stays as a ghost: the new owner receives the very same record in this exchange but cannot send it back before the next one.
 __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
-                                                    uint32_t halo, uint32_t has_l, uint32_t has_r, const uint2* __restrict__ blk,
-                                                    HaloRec* __restrict__ out_l, HaloRec* __restrict__ out_r, uint32_t cap) {
-    __shared__ uint32_t wl[4], wr[4];
+                                                    uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap) {
+    __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    bool fl = false, fr = false;
     float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t id = 0;
+    uint32_t id = 0, m = 0;
     if (i < n) {
         pv = PV[i];
         id = pid[i];
-        tile_send_flags(K, halo, pv, id, has_l != 0, has_r != 0, fl, fr);
+        m = tile_send_mask(K, P, halo, pv, id);
     }
-    const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
-    if (lane == 0) {
-        wl[w] = (uint32_t)__popcll(ml);
-        wr[w] = (uint32_t)__popcll(mr);
+    unsigned long long bal[MAX_TILE_PEERS];
+#pragma unroll
+    for (uint32_t k = 0; k < MAX_TILE_PEERS; ++k) {
+        bal[k] = k < P.n ? __ballot((m >> k) & 1u) : 0ull;
+        if (lane == 0) wc[w][k] = (uint32_t)__popcll(bal[k]);
     }
     __syncthreads();
     if (i >= n) return;
-    if (fl || fr) {
-        const uint2 base = blk[blockIdx.x];
+    if (m) {
         const unsigned long long below = (1ull << lane) - 1ull;
         HaloRec r;
         r.pv = pv;
@@ -564,21 +564,20 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
         r.kappa = kappa[i];
         r.stiff = stiff[i];
         r.pad = 0;
-        if (fl) {
-            uint32_t k = base.x + (uint32_t)__popcll(ml & below);
-            for (uint32_t q = 0; q < w; ++q) k += wl[q];
-            if (k < cap) out_l[1 + k] = r;  // record 0 is the header (count)
-        }
-        if (fr) {
-            uint32_t k = base.y + (uint32_t)__popcll(mr & below);
-            for (uint32_t q = 0; q < w; ++q) k += wr[q];
-            if (k < cap) out_r[1 + k] = r;
+#pragma unroll
+        for (uint32_t k = 0; k < MAX_TILE_PEERS; ++k) {
+            if ((m >> k) & 1u) {
+                uint32_t slot = blk[(size_t)blockIdx.x * MAX_TILE_PEERS + k] + (uint32_t)__popcll(bal[k] & below);
+                for (uint32_t q = 0; q < w; ++q) slot += wc[q][k];
+                if (slot < cap) P.out[k][1 + slot] = r;  // record 0 is the header (count)
+            }
         }
     }
     const bool valid = (id >> 31) != 0 && pv.x == pv.x;
-    const uint32_t c = tile_coord(K, pv.x, pv.y);
-    const bool own = c >= K.tile_lo && c < K.tile_hi;
-    const bool ghost = c + halo >= K.tile_lo && c < K.tile_hi + halo;
+    uint32_t cx, cy;
+    cell_of(K, make_float2(pv.x, pv.y), cx, cy);
+    const bool own = rect_has(K.tile, cx, cy, 0u);
+    const bool ghost = rect_has(K.tile, cx, cy, halo);
     if (valid && own) return;
     if (valid && ghost) {
         pid[i] = id & 0x7FFFFFFFu;
@@ -588,16 +587,18 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
     PV[i].x = nan;
     posA[i].x = nan;
 }
-// append the received records behind the current particles; unused slots up to n_base + 2*cap are marked dropped
-__global__ __launch_bounds__(256) void k_tile_apply(const HaloRec* __restrict__ from_l, const HaloRec* __restrict__ from_r, uint32_t cap,
-                                                     uint32_t n_base, Consts K, uint32_t halo, float4* __restrict__ PV, float2* __restrict__ posA,
-                                                     uint32_t* __restrict__ pid, float* __restrict__ kappa, float* __restrict__ stiff,
-                                                     DevScalars* __restrict__ scal) {
+// append the received records (peer after peer, `cap` slots each) behind the current particles; unused slots are marked dropped
+struct TileInbox {
+    uint32_t n;
+    const HaloRec* in[MAX_TILE_PEERS];  // nullptr: nothing from that peer
+};
+__global__ __launch_bounds__(256) void k_tile_apply(TileInbox B, uint32_t cap, uint32_t n_base, Consts K, uint32_t halo, float4* __restrict__ PV,
+                                                     float2* __restrict__ posA, uint32_t* __restrict__ pid, float* __restrict__ kappa,
+                                                     float* __restrict__ stiff, DevScalars* __restrict__ scal) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= 2 * cap) return;
-    const bool right = r >= cap;
-    const HaloRec* src = right ? from_r : from_l;
-    const uint32_t k = right ? r - cap : r;
+    if (r >= B.n * cap) return;
+    const uint32_t peer = r / cap, k = r - peer * cap;
+    const HaloRec* src = B.in[peer];
     uint32_t cnt = src ? src[0].id : 0u;  // header
     if (cnt > cap) {
         cnt = cap;
@@ -612,9 +613,10 @@ __global__ __launch_bounds__(256) void k_tile_apply(const HaloRec* __restrict__ 
         return;
     }
     const HaloRec rec = src[1 + k];
-    const uint32_t c = tile_coord(K, rec.pv.x, rec.pv.y);
-    const bool own = c >= K.tile_lo && c < K.tile_hi;
-    const bool ghost = c + halo >= K.tile_lo && c < K.tile_hi + halo;
+    uint32_t cx, cy;
+    cell_of(K, make_float2(rec.pv.x, rec.pv.y), cx, cy);
+    const bool own = rect_has(K.tile, cx, cy, 0u);
+    const bool ghost = rect_has(K.tile, cx, cy, halo);
     float4 pv = rec.pv;
     if (!own && !ghost) pv.x = nan;
     PV[dst] = pv;

@@ -1,10 +1,12 @@
 """Spatial-tile (multi-GPU) driver of the DFSPH step — SURVEY.md §8(e), DESIGN.md §7.
 
-The reference (yasph2d) has no distributed path.  The domain is cut into strips along one axis at cell boundaries; rank r
-OWNS the particles whose cell coordinate lies in [cuts[r], cuts[r+1]) and additionally holds GHOST copies of the neighbours'
-particles within `halo` cells of its cuts.  One process per GPU; the only per-step collectives are
+The reference (yasph2d) has no distributed path.  The domain is cut at cell boundaries into rectangles — strips along one axis
+(`StripLayout`, the 8-GPU layout) or columns that are cut again across (`GridLayout`, 2x2 on 4 GPUs); rank r OWNS the particles
+whose cell lies in its rectangle and additionally holds GHOST copies of its neighbours' particles within `halo` cells of it.
+One process per GPU; the only per-step collectives are
 
-  * one halo exchange (32-byte particle records, send/recv with the <= 2 spatial neighbours) between advect and re-grid:
+  * one halo exchange (32-byte particle records, send/recv with the <= 8 spatial neighbours; 2 for strips) between advect and
+    re-grid:
     it carries migration (particles that crossed a cut) and rebuilds the ghost set from scratch, and
   * three tiny all-reduces: max |v + a dt|^2 (CFL, dfsph.rs:474-479) and the residual sum + owned count of every solver
     iteration (dfsph.rs:221, :377).
@@ -78,6 +80,78 @@ def rebalance_cuts(cuts, counts, halo, columns, max_shift, threshold=1.05):
     return new
 
 
+def grow(rect, halo):
+    x0, x1, y0, y1 = rect
+    return (max(0, x0 - halo), min(65536, x1 + halo), max(0, y0 - halo), min(65536, y1 + halo))
+
+
+def rects_touch(a, b, halo):
+    """True if rectangle b grown by `halo` cells overlaps a (the relation is symmetric)."""
+    gx0, gx1, gy0, gy1 = b[0] - halo, b[1] + halo, b[2] - halo, b[3] + halo
+    return a[0] < gx1 and gx0 < a[1] and a[2] < gy1 and gy0 < a[3]
+
+
+def in_rect(cx, cy, rect, halo=0):
+    x0, x1, y0, y1 = rect
+    return (cx + halo >= x0) & (cx < x1 + halo) & (cy + halo >= y0) & (cy < y1 + halo)
+
+
+class StripLayout:
+    """`world` strips along `axis`; rank r owns [cuts[r], cuts[r+1]) x everything."""
+
+    def __init__(self, axis, cuts):
+        self.axis, self.cuts = int(axis), list(cuts)
+        self.world = len(self.cuts) - 1
+
+    def rects(self):
+        full = (0, 65536)
+        return [((self.cuts[r], self.cuts[r + 1]) + full) if self.axis == 0 else (full + (self.cuts[r], self.cuts[r + 1])) for r in range(self.world)]
+
+    def state(self):
+        return list(self.cuts)
+
+    def rebalance(self, counts, halo, columns, max_shift):
+        new = rebalance_cuts(self.cuts, counts, halo, columns[self.axis], max_shift)
+        changed = new != self.cuts
+        self.cuts = new
+        return changed
+
+
+class GridLayout:
+    """nx columns cut at xcuts, each column cut again at its own ycuts[ix] (SURVEY.md 8(e): "x-cut then per-column y-cut");
+    rank = ix * ny + iy."""
+
+    def __init__(self, xcuts, ycuts):
+        self.xcuts, self.ycuts = list(xcuts), [list(c) for c in ycuts]
+        self.nx, self.ny = len(self.xcuts) - 1, len(self.ycuts[0]) - 1
+        self.world = self.nx * self.ny
+
+    @staticmethod
+    def quantile(pos, nx, ny, grid_min=-100.0, h=0.02):
+        cx, cy = cell_coord(pos, 0, grid_min, h=h), cell_coord(pos, 1, grid_min, h=h)
+        xcuts = quantile_cuts(cx, nx)
+        ycuts = []
+        for ix in range(nx):
+            m = (cx >= xcuts[ix]) & (cx < xcuts[ix + 1])
+            ycuts.append(quantile_cuts(cy[m], ny) if m.any() else quantile_cuts(cy, ny))
+        return GridLayout(xcuts, ycuts)
+
+    def rects(self):
+        return [(self.xcuts[ix], self.xcuts[ix + 1], self.ycuts[ix][iy], self.ycuts[ix][iy + 1]) for ix in range(self.nx) for iy in range(self.ny)]
+
+    def state(self):
+        return [list(self.xcuts)] + [list(c) for c in self.ycuts]
+
+    def rebalance(self, counts, halo, columns, max_shift):
+        before = self.state()
+        col = [sum(counts[ix * self.ny:(ix + 1) * self.ny]) for ix in range(self.nx)]
+        self.xcuts = rebalance_cuts(self.xcuts, col, halo, columns[0], max_shift)
+        for ix in range(self.nx):
+            # a column holds 1/nx of the particles: its rows are that much thinner
+            self.ycuts[ix] = rebalance_cuts(self.ycuts[ix], counts[ix * self.ny:(ix + 1) * self.ny], halo, columns[1] / self.nx, max_shift)
+        return self.state() != before
+
+
 class TorchComm:
     """torch.distributed: backend "nccl" IS RCCL on ROCm (device tensors over xGMI); "gloo" in the CPU tests."""
 
@@ -85,32 +159,31 @@ class TorchComm:
         self.dist, self.device = dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def exchange(self, send_left, send_right, recv_left, recv_right, stream_ordered=False):
-        """stream_ordered: the caller's kernels run on torch's CURRENT stream (GpuTileBackend.stream_context), so the collective
-        library's stream semantics order pack -> send/recv -> unpack and no host synchronisation is needed."""
+    def exchange(self, peers, sends, recvs, stream_ordered=False):
+        """Send sends[k] to rank peers[k] and receive recvs[k] from it, all peers at once.  stream_ordered: the caller's kernels
+        run on torch's CURRENT stream (GpuTileBackend.stream_context), so the collective library's stream semantics order
+        pack -> send/recv -> unpack and no host synchronisation is needed."""
         import torch
         import torch.distributed as dist
 
+        if not peers:
+            return
         # gloo cannot send device tensors: stage through the host (functional tests on a single-GPU box); RCCL sends the
         # device buffers as they are.
-        stage = dist.get_backend() == "gloo" and send_left.is_cuda
-        sl, sr = (send_left.cpu(), send_right.cpu()) if stage else (send_left, send_right)
-        rl, rr = (torch.empty_like(sl), torch.empty_like(sr)) if stage else (recv_left, recv_right)
+        cuda = sends[0].is_cuda
+        stage = dist.get_backend() == "gloo" and cuda
+        ss = [t.cpu() for t in sends] if stage else sends
+        rs = [torch.empty_like(t) for t in ss] if stage else recvs
         ops = []
-        if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, sl, self.rank - 1), dist.P2POp(dist.irecv, rl, self.rank - 1)]
-        if self.rank < self.world - 1:
-            ops += [dist.P2POp(dist.isend, sr, self.rank + 1), dist.P2POp(dist.irecv, rr, self.rank + 1)]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if stage:
-                if self.rank > 0:
-                    recv_left.copy_(rl)
-                if self.rank < self.world - 1:
-                    recv_right.copy_(rr)
-            if send_left.is_cuda and not stream_ordered:
-                torch.cuda.synchronize(send_left.device)
+        for k, peer in enumerate(peers):
+            ops += [dist.P2POp(dist.isend, ss[k], peer), dist.P2POp(dist.irecv, rs[k], peer)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if stage:
+            for k in range(len(peers)):
+                recvs[k].copy_(rs[k])
+        if cuda and not stream_ordered:
+            torch.cuda.synchronize(sends[0].device)
 
     def _red_device(self):
         import torch
@@ -183,20 +256,17 @@ class ThreadComm:
     def __init__(self, shared, rank):
         self.sh, self.rank, self.world = shared, rank, shared.world
 
-    def exchange(self, send_left, send_right, recv_left, recv_right, stream_ordered=False):
-        if send_left.is_cuda:
+    def exchange(self, peers, sends, recvs, stream_ordered=False):
+        cuda = bool(sends) and sends[0].is_cuda
+        if cuda:
             import torch
 
             torch.cuda.synchronize()  # the other thread reads these buffers from its own stream
-        self.sh.slots[self.rank]["L"], self.sh.slots[self.rank]["R"] = send_left, send_right
+        self.sh.slots[self.rank]["send"] = dict(zip(peers, sends))
         self.sh.barrier.wait()
-        if self.rank > 0:
-            recv_left.copy_(self.sh.slots[self.rank - 1]["R"])
-        if self.rank < self.world - 1:
-            recv_right.copy_(self.sh.slots[self.rank + 1]["L"])
-        if recv_left.is_cuda:
-            import torch
-
+        for k, peer in enumerate(peers):
+            recvs[k].copy_(self.sh.slots[peer]["send"][self.rank])
+        if cuda:
             torch.cuda.synchronize()
         self.sh.barrier.wait()
 
@@ -242,18 +312,20 @@ class GpuTileBackend:
         if rc:
             raise SphxError(rc, self.L.sphx_last_error(self.ctx.h).decode())
 
-    def make_buffers(self, cap):
+    def make_buffers(self, cap, count):
         n = (1 + cap) * HALO_RECORD_BYTES
         with self.stream_context():
-            bufs = [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(4)]
+            bufs = [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(count)]
         self.torch.cuda.synchronize(self.device)
         return bufs
 
     def set_boundary(self, xy):
         self.ctx.set_boundary(xy)
 
-    def configure(self, axis, lo, hi, halo, has_left, has_right):
-        self._chk(self.L.sphx_tile_configure(self.ctx.h, axis, lo, hi, halo, int(has_left), int(has_right)))
+    def configure(self, own, halo, peer_rects):
+        rect = C.c_uint32 * 4
+        peers = (rect * max(1, len(peer_rects)))(*[rect(*r) for r in peer_rects])
+        self._chk(self.L.sphx_tile_configure_rect(self.ctx.h, rect(*own), halo, peers, len(peer_rects)))
 
     def reserve(self, capacity):
         self._chk(self.L.sphx_reserve(self.ctx.h, capacity))
@@ -265,12 +337,13 @@ class GpuTileBackend:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._chk(self.L.sphx_tile_upload(self.ctx.h, p(pos), p(vel), p(ids), len(pos)))
 
-    def pack(self, send_left, send_right, cap):
-        self._chk(self.L.sphx_tile_pack(self.ctx.h, C.c_void_p(send_left.data_ptr()), C.c_void_p(send_right.data_ptr()), cap))
+    def pack(self, sends, cap):
+        ptrs = (C.c_void_p * max(1, len(sends)))(*[t.data_ptr() for t in sends])
+        self._chk(self.L.sphx_tile_pack_n(self.ctx.h, ptrs, len(sends), cap))
 
-    def apply(self, recv_left, recv_right, cap):
-        self._chk(self.L.sphx_tile_apply(self.ctx.h, C.c_void_p(recv_left.data_ptr()) if recv_left is not None else None,
-                                         C.c_void_p(recv_right.data_ptr()) if recv_right is not None else None, cap))
+    def apply(self, recvs, cap):
+        ptrs = (C.c_void_p * max(1, len(recvs)))(*[t.data_ptr() for t in recvs])
+        self._chk(self.L.sphx_tile_apply_n(self.ctx.h, ptrs, len(recvs), cap))
 
     def regrid(self):
         n = C.c_uint32()
@@ -309,15 +382,20 @@ class GpuTileBackend:
 
 # -------------------------------------------------------------------------------------------------------------------- driver
 class TiledDFSPH:
-    """Solver::simulation_step (dfsph.rs:414-525) over spatial tiles.  All ranks call the same methods in lockstep."""
+    """Solver::simulation_step (dfsph.rs:414-525) over spatial tiles.  All ranks call the same methods in lockstep.
 
-    def __init__(self, backend, comm, axis, cuts, halo=16, cap_records=None, max_avg_density_error=np.float32(0.01) / np.float32(100.0),
+    layout: StripLayout / GridLayout (identical on every rank); the historical form TiledDFSPH(backend, comm, axis, cuts, ...)
+    builds a StripLayout."""
+
+    def __init__(self, backend, comm, layout, cuts=None, halo=16, cap_records=None, max_avg_density_error=np.float32(0.01) / np.float32(100.0),
                  max_density_iterations=200, max_divergence_error=np.float32(0.1) / np.float32(100.0), max_divergence_iterations=400,
                  fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0, rebalance_every=0):
-        self.b, self.comm, self.axis, self.cuts, self.halo = backend, comm, axis, list(cuts), int(halo)
+        if cuts is not None:
+            layout = StripLayout(layout, cuts)
+        self.b, self.comm, self.layout, self.halo = backend, comm, layout, int(halo)
         self.rank, self.world = comm.rank, comm.world
-        self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
-        self.has_left, self.has_right = self.rank > 0, self.rank < self.world - 1
+        if layout.world != self.world:
+            raise ValueError("layout and communicator disagree about the number of tiles")
         self.tol_d, self.max_d = np.float32(max_avg_density_error), int(max_density_iterations)
         self.tol_v, self.max_v = np.float32(max_divergence_error), int(max_divergence_iterations)
         self.fixed = fixed_iterations
@@ -328,8 +406,41 @@ class TiledDFSPH:
         self.cap = cap_records
         self.exchanges = 0
         self.rebalance_every, self.rebalances, self._steps = int(rebalance_every), 0, 0
-        self.boundary_margin = 256  # extra cells of boundary particles kept on either side (cuts may drift that far before a re-clip)
+        self.boundary_margin = 256  # extra cells of boundary particles kept on every side (cuts may drift that far before a re-clip)
         self._valid = self._kvalid = float("inf")
+        self._bufs = {}
+
+    # historical accessors of the strip form (tests, bench)
+    @property
+    def axis(self):
+        return getattr(self.layout, "axis", None)
+
+    @property
+    def cuts(self):
+        return self.layout.state()
+
+    # ---- geometry -----------------------------------------------------------------------------------------------------------
+    def _place(self):
+        """Own rectangle and the peers (tiles whose rectangle grown by the halo touches it), from the layout."""
+        rects = self.layout.rects()
+        self.rect = rects[self.rank]
+        self.peers = [k for k in range(self.world) if k != self.rank and rects_touch(self.rect, rects[k], self.halo)]
+        if len(self.peers) > 8:
+            raise ValueError("a tile touches more than 8 others: tiles are too small for this halo")
+        for k in [self.rank] + self.peers:  # interior extents must hold two halo widths (ghosts come from direct neighbours only)
+            x0, x1, y0, y1 = rects[k]
+            if (x0 > 0 and x1 < 65536 and x1 - x0 < 2 * self.halo) or (y0 > 0 and y1 < 65536 and y1 - y0 < 2 * self.halo):
+                raise ValueError("tiles must be at least two halo widths wide")
+        self.peer_rects = [rects[k] for k in self.peers]
+        self.b.configure(self.rect, self.halo, self.peer_rects)
+
+    def _buffers(self):
+        need = [k for k in self.peers if k not in self._bufs]
+        if need:
+            new = self.b.make_buffers(self.cap, 2 * len(need))
+            for j, k in enumerate(need):
+                self._bufs[k] = (new[2 * j], new[2 * j + 1])
+        return [self._bufs[k][0] for k in self.peers], [self._bufs[k][1] for k in self.peers]
 
     # ---- setup ------------------------------------------------------------------------------------------------------------
     def setup(self, pos, vel, ids, boundary):
@@ -337,37 +448,37 @@ class TiledDFSPH:
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
         vel = np.zeros_like(pos) if vel is None else np.ascontiguousarray(vel, np.float32).reshape(-1, 2)
         ids = np.arange(len(pos), dtype=np.uint32) if ids is None else np.asarray(ids, np.uint32)
-        c = cell_coord(pos, self.axis, self.grid_min, h=self.h)
-        mine = (c >= self.lo) & (c < self.hi)
+        cx, cy = cell_coord(pos, 0, self.grid_min, h=self.h), cell_coord(pos, 1, self.grid_min, h=self.h)
+        self._place()
+        mine = in_rect(cx, cy, self.rect)
         n_own = int(mine.sum())
-        if self.world > 1:
-            widths = [self.cuts[r + 1] - self.cuts[r] for r in range(1, self.world - 1)]
-            if any(w < 2 * self.halo for w in widths) or (self.world > 1 and min(self.hi, 65536) - self.lo < 2 * self.halo and 0 < self.rank < self.world - 1):
-                raise ValueError("tiles must be at least two halo widths wide")
         if self.cap is None:
-            # particles within `halo` cells of a cut: estimate from the global scene, with head-room for compression waves
+            # particles this tile has to send to one peer: estimate from the global scene, with head-room for compression waves
+            rects = self.layout.rects()
             near = 0
-            for cut in self.cuts[1:-1]:
-                near = max(near, int(((c >= cut - self.halo) & (c < cut)).sum()), int(((c >= cut) & (c < cut + self.halo)).sum()))
+            for a in range(self.world):
+                ma = in_rect(cx, cy, rects[a])
+                for b in range(self.world):
+                    if a != b and rects_touch(rects[a], rects[b], self.halo):
+                        near = max(near, int((ma & in_rect(cx, cy, rects[b], self.halo)).sum()))
             self.cap = max(1024, int(near * 1.5) + 1024)
-        self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
-        self.b.reserve(int(n_own * 1.25) + 4 * self.cap + 4096)
-        self.columns = len(pos) / max(1, int(c.max()) - int(c.min()) + 1) if len(pos) else 1.0
+        self.b.reserve(int(n_own * 1.25) + 2 * max(2, len(self.peers)) * self.cap + 4096)
+        span = lambda c: max(1, int(c.max()) - int(c.min()) + 1) if len(c) else 1  # noqa: E731
+        self.columns = (len(pos) / span(cx), len(pos) / span(cy))  # mean particles per cell column / cell row
         self.n_owned_local = n_own
         self.boundary = None
         if boundary is not None and len(boundary):
             self.boundary = np.ascontiguousarray(boundary, np.float32).reshape(-1, 2)
-            self.boundary_cells = cell_coord(self.boundary, self.axis, self.grid_min, h=self.h)
+            self.boundary_cells = (cell_coord(self.boundary, 0, self.grid_min, h=self.h), cell_coord(self.boundary, 1, self.grid_min, h=self.h))
             self._clip_boundary()
         self.b.upload(pos[mine], vel[mine], ids[mine])
-        self.bufs = self.b.make_buffers(self.cap)
         self.n_owned_global = len(pos)
         self.refresh()  # initial ghosts + the warm-up block (dfsph.rs:419-428): re-grid, densities, alpha
 
     def _clip_boundary(self):
         m = self.halo + 2 + (self.boundary_margin if self.rebalance_every else 0)
-        self._clip_lo, self._clip_hi = self.lo, self.hi
-        keep = (self.boundary_cells + m >= self.lo) & (self.boundary_cells < self.hi + m)
+        self._clip_rect = self.rect
+        keep = in_rect(self.boundary_cells[0], self.boundary_cells[1], self.rect, m)
         self.b.set_boundary(self.boundary[keep])
 
     # ---- load balance -------------------------------------------------------------------------------------------------------
@@ -379,16 +490,13 @@ class TiledDFSPH:
         return out
 
     def rebalance(self):
-        """Move the cuts towards equal owned counts; takes effect in the refresh() that follows (the pack/drop/apply rules are
+        """Move the cuts towards equal owned counts; takes effect in the refresh() that follows (the pack/retire/apply rules are
         purely geometric, so particles of the band that changes owner travel as ordinary migrants)."""
         counts = self._allgather(self.n_owned_local)
-        new = rebalance_cuts(self.cuts, counts, self.halo, self.columns, max_shift=max(1, self.halo // 4))
-        if new == self.cuts:
+        if not self.layout.rebalance(counts, self.halo, self.columns, max(1, self.halo // 4)):
             return False
-        self.cuts = new
-        self.lo, self.hi = new[self.rank], new[self.rank + 1]
-        self.b.configure(self.axis, self.lo, self.hi, self.halo, self.has_left, self.has_right)
-        if self.boundary is not None and max(abs(self.lo - self._clip_lo), abs(self.hi - self._clip_hi)) > self.boundary_margin // 2:
+        self._place()
+        if self.boundary is not None and max(abs(a - b) for a, b in zip(self.rect, self._clip_rect)) > self.boundary_margin // 2:
             self._clip_boundary()
         self.rebalances += 1
         return True
@@ -396,12 +504,12 @@ class TiledDFSPH:
     # ---- halo ---------------------------------------------------------------------------------------------------------------
     def refresh(self):
         """Halo exchange (migration + fresh ghosts) followed by the re-grid of the local set."""
-        sl, sr, rl, rr = self.bufs
-        self.b.pack(sl, sr, self.cap)
+        sends, recvs = self._buffers()
+        self.b.pack(sends, self.cap)
         ordered = getattr(self.b, "stream", None) is not None  # kernels and communication share one stream: no host sync
         with (self.b.stream_context() if ordered else contextlib.nullcontext()):
-            self.comm.exchange(sl, sr, rl, rr, stream_ordered=ordered)
-        self.b.apply(rl if self.has_left else None, rr if self.has_right else None, self.cap)
+            self.comm.exchange(self.peers, sends, recvs, stream_ordered=ordered)
+        self.b.apply(recvs, self.cap)
         self.n_local = self.b.regrid()
         self.exchanges += 1
         full = float("inf") if self.world == 1 else float(self.halo)
