@@ -713,8 +713,12 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
     }
 }
 
+// 7 waves per SIMD: what the 22.5 KiB of LDS per workgroup allow (7 workgroups per CU); one VGPR less than the unconstrained allocation
+#ifndef NB_BOUNDS
+#define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
+#endif
 template <bool FUSE>
-__global__ __launch_bounds__(256) void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
+__global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
                                                          uint2* __restrict__ bases, float* __restrict__ density, float* __restrict__ alpha,
                                                          DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
