@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t* __restrict__ in, u
 // The value returned by the atomic is an arbitrary arrival slot inside the cell; k_rank_gather restores the stable order.
 // cidx[i] = the particle's index into the fine table (kept for scatter/gather).
 template <bool ADVECT>
-__global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, float2* __restrict__ posA, const float2* __restrict__ pos_in,
+__global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV, const float2* __restrict__ pos_in,
                                                     uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
                                                     uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
                                                     DevScalars* __restrict__ scal) {
@@ -322,12 +322,10 @@ __global__ __launch_bounds__(256) void k_key_count(float4* __restrict__ PV, floa
     if (i < n) {
         float2 p;
         if (ADVECT) {
-            float4 pv = PV[i];
-            pv.x = pv.x + pv.z * dt;
-            pv.y = pv.y + pv.w * dt;
-            PV[i] = pv;
-            p = make_float2(pv.x, pv.y);
-            posA[i] = p;
+            // the advected position is only needed for the key here; k_rank_gather repeats the same two operations when it moves
+            // the record, so this pass writes neither PV nor posA (24 B per particle less)
+            const float4 pv = PV[i];
+            p = make_float2(pv.x + pv.z * dt, pv.y + pv.w * dt);
         } else {
             p = pos_in[i];
         }
@@ -382,6 +380,7 @@ struct GatherArgs {
     const uint32_t* u_in;  // particle id; bit 31 = owned by this tile
     uint32_t* u_out;
     DevScalars* count_owned;  // tile mode: counts ids with bit 31 set
+    float advect_dt;          // > 0: the fluid build inside a step — positions advance by v*dt while the records move
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
@@ -407,7 +406,11 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     const uint32_t dst = s + rank;
     if (dst >= n) return;
     if (a.pv_in) {
-        const float4 pv = a.pv_in[i];
+        float4 pv = a.pv_in[i];
+        if (a.advect_dt > 0.0f) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
+            pv.x = pv.x + pv.z * a.advect_dt;
+            pv.y = pv.y + pv.w * a.advect_dt;
+        }
         a.pv_out[dst] = pv;
         a.pos_out[dst] = make_float2(pv.x, pv.y);
     } else {
