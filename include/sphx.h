@@ -277,6 +277,8 @@ uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float particle_diamete
 uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t);
 uint32_t sphx_timer_num_steps(const sphx_timer* t);
 int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_law* out); /* fills sphx_timer_law from the mirror */
+void sphx_timer_set_target_frame(sphx_timer* t, uint64_t target_ns); /* AdaptiveTimeStepTarget::TargetFrameLength, timemanager.rs:24-36; 0 = None */
+void sphx_timer_on_step_started(sphx_timer* t);                      /* the clock part of simulation_frame_loop, timemanager.rs:244-247 */
 
 /* DFSPHSolver::new(XSPHViscosityModel::new(h), h) boxed as dyn Solver (main.rs:93-101).  `params` may be NULL (defaults from the world). */
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out);

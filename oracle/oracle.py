@@ -85,6 +85,8 @@ def lib(omp=False):
         "orc_get_properties": (None, [vp, vp]),
         "orc_timer_adaptive": (None, [vp, u64, u64, f32]),
         "orc_timer_fixed": (None, [vp, u64]),
+        "orc_timer_target_frame": (None, [vp, u64]),
+        "orc_timer_on_step_started": (None, [vp]),
         "orc_timer_step_ns": (u64, [vp]),
         "orc_timer_update": (u64, [vp, f32, f32]),
         "orc_set_boundary": (None, [vp, vp, u32]),
@@ -171,6 +173,12 @@ class Oracle:
 
     def timer_adaptive(self, tmax_ns, tmin_ns, cfl):
         self.L.orc_timer_adaptive(self.h, tmax_ns, tmin_ns, cfl)
+
+    def timer_target_frame(self, target_ns):
+        self.L.orc_timer_target_frame(self.h, target_ns)
+
+    def timer_on_step_started(self):
+        self.L.orc_timer_on_step_started(self.h)
 
     def timer_fixed(self, step_ns):
         self.L.orc_timer_fixed(self.h, step_ns)

@@ -293,13 +293,17 @@ struct TimeManager {
     Real cfl_factor;
     bool fixed;
     uint64_t simulation_step_ns;
+    uint64_t target_frame_ns = 0;     // AdaptiveTimeStepTarget::TargetFrameLength (timemanager.rs:24-36), 0 = None
+    uint64_t total_simulated_ns = 0;  // advanced by simulation_frame_loop (timemanager.rs:246)
     void init_adaptive(uint64_t tmax, uint64_t tmin, Real cfl) {
         timestep_max_ns = tmax;
         timestep_min_ns = tmin;
         cfl_factor = cfl;
         fixed = false;
         simulation_step_ns = tmin;  // timemanager.rs:106-109
+        total_simulated_ns = 0;
     }
+    void on_step_started() { total_simulated_ns += simulation_step_ns; }  // timemanager.rs:244-247
     void init_fixed(uint64_t step) {
         fixed = true;
         timestep_max_ns = timestep_min_ns = simulation_step_ns = step;
@@ -311,7 +315,11 @@ struct TimeManager {
             const Real VELOCITY_EPSILON = 0.00001f;
             const uint64_t time_cfl = duration_from_secs_f32(cfl_factor * 0.4f * particle_diameter / (max_velocity + VELOCITY_EPSILON));
             const uint64_t upper_bound = std::min(timestep_max_ns, simulation_step_ns * 2);
-            const uint64_t lower_bound = timestep_min_ns;  // AdaptiveTimeStepTarget::None (main.rs:125)
+            uint64_t lower_bound = timestep_min_ns;  // AdaptiveTimeStepTarget::None (main.rs:125)
+            if (target_frame_ns) {                   // timemanager.rs:268-272, literally (the remainder since the last multiple)
+                const uint64_t time_to_target = total_simulated_ns - target_frame_ns * (uint64_t)(uint32_t)(total_simulated_ns / target_frame_ns);
+                lower_bound = std::min(timestep_min_ns, time_to_target);
+            }
             simulation_step_ns = std::max(lower_bound, std::min(upper_bound, time_cfl));
         }
         return simulation_step_ns;
@@ -1240,6 +1248,8 @@ void orc_dfsph_step(OrcSim* s, StepStats* out) {
     s->dfsph.simulation_step(s->world, s->timer, s->last);
     if (out) *out = s->last;
 }
+void orc_timer_target_frame(OrcSim* s, uint64_t target_ns) { s->timer.target_frame_ns = target_ns; }
+void orc_timer_on_step_started(OrcSim* s) { s->timer.on_step_started(); }
 void orc_wcsph_clear_cached(OrcSim* s) { s->wcsph.accellerations.clear(); }
 void orc_wcsph_step(OrcSim* s, StepStats* out) {
     s->wcsph.simulation_step(s->world, s->timer, s->last);

@@ -139,6 +139,28 @@ def test_dfsph_host_driven_dt():
     run_steps(ctx, o, 250, check_every=50, use_law=False)
 
 
+def test_target_frame_timer_with_device_law():
+    """TargetFrameLength timer (timemanager.rs:268-274): the lower bound the host passes in the law changes every step."""
+    pos, boundary = dam_break(1.0)
+    ctx, o = make_pair(pos, boundary)
+    timer = y.TimeManager()
+    target = 2_000_000  # 2 ms frames: the bound drops below timestep_min regularly
+    timer.set_target_frame(target)
+    o.timer_target_frame(target)
+    diam = np.float32(0.01)
+    for s in range(300):
+        timer.on_step_started()
+        o.timer_on_step_started()
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+        dt_ns = timer.update_simulation_step(diam, vmax)
+        ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+        o.dfsph_step()
+        assert o.timer_step_ns() == dt_ns, s
+    d = ctx.download()
+    assert_bits_equal(d["pos"], o.positions(), "positions")
+    assert_bits_equal(d["vel"], o.velocities(), "velocities")
+
+
 def test_timer_law_mismatch_is_detected():
     """A law that is not the one the host timer applies: step_finish refuses the host's dt and asks for a new upload."""
     pos, boundary = dam_break(1.0)

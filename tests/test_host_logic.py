@@ -67,6 +67,36 @@ def test_update_simulation_step_law_matches_oracle(oracle_lib):
         prev = got
 
 
+def test_target_frame_length_law(oracle_lib):
+    """AdaptiveTimeStepTarget::TargetFrameLength (timemanager.rs:268-274), restated literally: the lower bound becomes
+    min(timestep_min, total_simulated_time mod target).  Mirror vs oracle vs formula; the law handed to the device carries it."""
+    from oracle.oracle import Oracle
+
+    o = Oracle()
+    t = y.TimeManager()
+    target = 300_000
+    t.set_target_frame(target)
+    o.timer_target_frame(target)
+    rng = np.random.default_rng(9)
+    prev, total, lows = t.simulation_step_ns(), 0, set()
+    for vmax in rng.uniform(0, 30, 400):
+        vmax, d = np.float32(vmax), np.float32(0.01)
+        t.on_step_started()
+        o.timer_on_step_started()
+        total += prev
+        assert t.total_simulated_ns == total
+        low = min(t.timestep_min_ns, total - target * (total // target))
+        lows.add(low < t.timestep_min_ns)
+        law = t.law(d)
+        assert law.timestep_min_ns == low and law.simulation_step_ns == prev
+        cfl = exact_round_ns(np.float32(1.5) * np.float32(0.4) * d / (vmax + np.float32(0.00001)))
+        want = max(low, min(min(t.timestep_max_ns, 2 * prev), cfl))
+        got = t.update_simulation_step(d, vmax)
+        assert got == want == oracle_lib.orc_timer_update(o.h, d, vmax)
+        prev = got
+    assert lows == {True, False}, "both branches of the lower bound must have been taken"
+
+
 def test_fixed_timer():
     t = y.TimeManager(fixed_ns=1000000)
     assert t.update_simulation_step(np.float32(0.01), np.float32(5.0)) == 1000000

@@ -310,6 +310,14 @@ class TimeManager:
     def update_simulation_step(self, particle_diameter, max_velocity):
         return self.L.sphx_timer_update_simulation_step(self.h, particle_diameter, max_velocity)
 
+    def set_target_frame(self, target_ns):
+        """AdaptiveTimeStepTarget::TargetFrameLength (timemanager.rs:24-36); 0 = None."""
+        self.L.sphx_timer_set_target_frame(self.h, target_ns)
+
+    def on_step_started(self):
+        """The clock part of simulation_frame_loop (timemanager.rs:244-247): total simulated time advances by the current step."""
+        self.L.sphx_timer_on_step_started(self.h)
+
     def law(self, particle_diameter):
         """sphx_timer_law for SphxContext.step_begin: this timer's config and current step."""
         out = _lib.SphxTimerLaw()

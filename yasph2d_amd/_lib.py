@@ -98,6 +98,8 @@ SIGNATURES = {
     "sphx_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
     "sphx_step_begin_law": (_i, [_vp, _f, _vp, _vp]),
     "sphx_timer_law_of": (_i, [_vp, _f, _vp]),
+    "sphx_timer_set_target_frame": (None, [_vp, _u64]),
+    "sphx_timer_on_step_started": (None, [_vp]),
     "sphx_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
     "sphx_update_neighborhood": (_i, [_vp]),
     "sphx_update_densities": (_i, [_vp, _i]),

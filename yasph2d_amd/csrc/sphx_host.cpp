@@ -197,17 +197,22 @@ Duration TimeManager::update_simulation_step(Real particle_diameter, Real max_ve
         const Real VELOCITY_EPSILON = 0.00001f;
         const Duration time_cfl = Duration::from_secs_f32(cfl_factor * 0.4f * particle_diameter / (max_velocity + VELOCITY_EPSILON));
         const uint64_t upper_bound = std::min(timestep_max.ns, simulation_step_.mul(2).ns);
-        const uint64_t lower_bound = timestep_min.ns;  // AdaptiveTimeStepTarget::None (main.rs:125)
-        simulation_step_.ns = std::max(lower_bound, std::min(upper_bound, time_cfl.ns));
+        simulation_step_.ns = std::max(lower_bound().ns, std::min(upper_bound, time_cfl.ns));
     }
     return simulation_step_;
+}
+Duration TimeManager::lower_bound() const {  // timemanager.rs:268-274
+    if (timestep_target_frame.ns == 0) return timestep_min;  // AdaptiveTimeStepTarget::None (main.rs:125)
+    const uint64_t total = total_simulated_time.ns, target = timestep_target_frame.ns;
+    const uint64_t time_to_target = total - target * (uint64_t)(uint32_t)(total / target);  // literally: the remainder
+    return Duration{std::min(timestep_min.ns, time_to_target)};
 }
 void timer_law_of(const TimeManager& tm, Real particle_diameter, sphx_timer_law* out) {
     out->adaptive = tm.fixed ? 0u : 1u;
     out->cfl_factor = tm.fixed ? 1.0f : tm.cfl_factor;
     out->particle_diameter = particle_diameter;
     out->reserved = 0;
-    out->timestep_min_ns = tm.fixed ? tm.simulation_step_.ns : tm.timestep_min.ns;
+    out->timestep_min_ns = tm.fixed ? tm.simulation_step_.ns : tm.lower_bound().ns;
     out->timestep_max_ns = tm.fixed ? tm.simulation_step_.ns : tm.timestep_max.ns;
     out->simulation_step_ns = tm.simulation_step_.ns;
 }
@@ -396,6 +401,8 @@ uint64_t sphx_timer_simulation_step_ns(const sphx_timer* t) { return t->t.simula
 uint64_t sphx_timer_update_simulation_step(sphx_timer* t, float diameter, float vmax) { return t->t.update_simulation_step(diameter, vmax).ns; }
 uint64_t sphx_timer_total_simulated_ns(const sphx_timer* t) { return t->t.total_simulated_time.ns; }
 uint32_t sphx_timer_num_steps(const sphx_timer* t) { return t->t.num_simulation_steps; }
+void sphx_timer_set_target_frame(sphx_timer* t, uint64_t target_ns) { t->t.timestep_target_frame.ns = target_ns; }
+void sphx_timer_on_step_started(sphx_timer* t) { t->t.on_step_started(); }
 int sphx_timer_law_of(const sphx_timer* t, float particle_diameter, sphx_timer_law* out) {
     if (!t || !out) return SPHX_ERR_INVALID_ARGUMENT;
     sph::timer_law_of(t->t, particle_diameter, out);

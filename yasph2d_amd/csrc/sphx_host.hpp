@@ -79,6 +79,7 @@ struct TimeManager {
     Duration timestep_max, timestep_min;
     Real cfl_factor = 0;
     Duration simulation_step_;
+    Duration timestep_target_frame;  // AdaptiveTimeStepTarget::TargetFrameLength (timemanager.rs:24-36); zero = ::None
     uint32_t num_simulation_steps = 0;
     Duration total_simulated_time;
 
@@ -87,6 +88,7 @@ struct TimeManager {
     void restart();                                                               // :131-133
     Duration simulation_step() const { return simulation_step_; }                 // :136-138
     Duration update_simulation_step(Real particle_diameter, Real max_velocity);   // :252-279
+    Duration lower_bound() const;                                                 // :268-274, known before the update
     void on_step_started();  // the clock part of simulation_frame_loop (:244-247)
 };
 
