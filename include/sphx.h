@@ -112,6 +112,12 @@ int sphx_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, uint32_
  * place every step (neighborhood_search.rs:121-140).  particle_id[i] = index the particle had in the last sphx_upload. */
 int sphx_download(sphx_ctx* ctx, float* pos_xy, float* vel_xy, float* density, uint32_t* particle_id);
 int sphx_download_boundary(sphx_ctx* ctx, float* xy, uint32_t* boundary_id);
+/* Viewer feed (the app draws every particle at its position, coloured by |v|, main.rs:239-258): {x, y, |v|} of
+ * every stride-th particle, packed on the solver stream and copied to pinned host memory on a separate stream, so the transfer
+ * overlaps the following steps.  sphx_view_fetch returns the buffer of the latest request (3 floats per entry, valid until the next
+ * request); wait = 0 polls (SPHX_ERR_NOT_READY while the copy is in flight). */
+int sphx_view_request(sphx_ctx* ctx, uint32_t stride, uint32_t* out_count);
+int sphx_view_fetch(sphx_ctx* ctx, int wait, const float** out_xys, uint32_t* out_count);
 uint32_t sphx_num_particles(const sphx_ctx* ctx);  /* Particles::num_dynamic_particles  fluidparticleworld.rs:37 */
 uint32_t sphx_num_boundary(const sphx_ctx* ctx);   /* Particles::num_boundary_particles fluidparticleworld.rs:41 */
 

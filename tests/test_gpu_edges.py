@@ -151,3 +151,42 @@ def test_two_contexts_are_independent():
         step_both(b, ob, tb)
     compare_state(a, oa, "ctx a")
     compare_state(b, ob, "ctx b")
+
+
+def test_viewer_feed_strided_async_download():
+    """sphx_view_request / sphx_view_fetch: {x, y, |v|} of every stride-th particle, copied on a separate
+    stream while the simulation keeps stepping; equals the full download taken at the time of the request."""
+    pos, boundary = dam_break(2.0)
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    diam = np.float32(0.01)
+
+    def step():
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+        ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+
+    with pytest.raises(y.SphxError):
+        ctx.view_fetch()  # nothing requested yet
+    for _ in range(20):
+        step()
+    for stride in (1, 7, 1000, 10**9):
+        d = ctx.download()
+        m = ctx.view_request(stride)
+        assert m == (len(pos) + stride - 1) // stride
+        for _ in range(3):  # the copy overlaps these steps; the snapshot is the state at request time
+            step()
+        v = ctx.view_fetch()
+        assert v.shape == (m, 3)
+        assert_bits_equal(v[:, :2], d["pos"][::stride], f"stride {stride} positions")
+        speed = np.sqrt(d["vel"][::stride, 0] * d["vel"][::stride, 0] + d["vel"][::stride, 1] * d["vel"][::stride, 1])
+        assert_bits_equal(v[:, 2], speed.astype(np.float32), f"stride {stride} speed")
+    # polling form: eventually ready
+    ctx.view_request(3)
+    got = None
+    for _ in range(100000):
+        got = ctx.view_fetch(wait=False)
+        if got is not None:
+            break
+    assert got is not None and got.shape[1] == 3

@@ -103,6 +103,23 @@ class SphxContext:
         self._chk(self.L.sphx_step_finish(self.h, dt, C.byref(st)))
         return st.as_dict()
 
+    def view_request(self, stride=1):
+        """Start an asynchronous strided download of {x, y, |v|} (the viewer's per-frame data, main.rs:239-258)."""
+        n = C.c_uint32()
+        self._chk(self.L.sphx_view_request(self.h, stride, C.byref(n)))
+        return n.value
+
+    def view_fetch(self, wait=True):
+        """-> float32 array [count, 3] (a copy of the pinned buffer), or None if wait=False and the copy is still in flight."""
+        ptr, n = C.POINTER(C.c_float)(), C.c_uint32()
+        rc = self.L.sphx_view_fetch(self.h, int(wait), C.byref(ptr), C.byref(n))
+        if rc == _lib.ERR_NOT_READY and not wait:
+            return None
+        self._chk(rc)
+        if n.value == 0:
+            return np.zeros((0, 3), np.float32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value, 3)).copy()
+
     def wcsph_step_begin(self, dt):
         """WCSPHSolver::simulation_step up to the timer call (wscsph.rs:126-161) -> vmax."""
         v = C.c_float()

@@ -173,7 +173,13 @@ struct sphx_ctx {
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
-    bool external_stream = false;  // c->stream belongs to the caller (sphx_set_stream)
+    bool external_stream = false;
+    // viewer feed (sphx_view_request / sphx_view_fetch)
+    hipStream_t view_stream = nullptr;
+    hipEvent_t view_packed = nullptr, view_done = nullptr;
+    float *view_dev = nullptr, *view_host = nullptr;
+    uint32_t view_cap = 0, view_count = 0;
+    bool view_pending = false;  // c->stream belongs to the caller (sphx_set_stream)
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;

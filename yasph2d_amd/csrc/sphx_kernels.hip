@@ -1341,6 +1341,17 @@ __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos,
     cell_of(K, pos[i], cx, cy);
     key[i] = morton2(cx, cy);
 }
+// viewer feed (main.rs:239-258 draws every particle at its position, coloured by |v|): every stride-th
+// particle as {x, y, |v|}
+__global__ __launch_bounds__(256) void k_view_pack(const float4* __restrict__ PV, uint32_t n, uint32_t stride, float* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i = (uint64_t)k * stride;
+    if (i >= n) return;
+    const float4 pv = PV[i];
+    out[3 * (size_t)k + 0] = pv.x;
+    out[3 * (size_t)k + 1] = pv.y;
+    out[3 * (size_t)k + 2] = sqrtf(pv.z * pv.z + pv.w * pv.w);  // cgmath magnitude()
+}
 // publish the sticky flags / neighbour-entry count outside a solver step (sphx_update_neighborhood)
 __global__ void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {
     unsigned long long nb = 0;
