@@ -234,6 +234,8 @@ int sphx_set_stream(sphx_ctx* ctx, void* hip_stream);
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream; totals are kept per kernel name. */
 int sphx_profile_enable(sphx_ctx* ctx, int on);
 int sphx_profile_reset(sphx_ctx* ctx);
+int sphx_profile_filter(sphx_ctx* ctx, const char* label, uint32_t every); /* time only every `every`-th launch with this label (NULL = all
+                                                                              launches): light enough for a timed region */
 /* Fills up to *inout_n records; names are NUL-terminated, <= 47 chars. */
 typedef struct sphx_kernel_time {
     char name[48];

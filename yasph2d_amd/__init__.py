@@ -194,6 +194,10 @@ class SphxContext:
     def profile_enable(self, on=True):
         self._chk(self.L.sphx_profile_enable(self.h, int(on)))
 
+    def profile_filter(self, label=None, every=1):
+        """Time only every `every`-th launch with this label (None = all launches)."""
+        self._chk(self.L.sphx_profile_filter(self.h, label.encode() if label else None, every))
+
     def profile_reset(self):
         self._chk(self.L.sphx_profile_reset(self.h))
 

@@ -131,6 +131,7 @@ SIGNATURES = {
     "sphx_set_stream": (_i, [_vp, _vp]),
     "sphx_profile_enable": (_i, [_vp, _i]),
     "sphx_profile_reset": (_i, [_vp]),
+    "sphx_profile_filter": (_i, [_vp, C.c_char_p, _u32]),
     "sphx_profile_get": (_i, [_vp, _vp, C.POINTER(_u32)]),
     # host mirror
     "sphx_world_create": (_vp, [_f, _f, _f]),

@@ -173,6 +173,8 @@ struct sphx_ctx {
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
+    std::string prof_filter;  // sphx_profile_filter: only launches with this label are timed, every prof_every-th of them
+    uint32_t prof_every = 1, prof_counter = 0;
     bool external_stream = false;
     // viewer feed (sphx_view_request / sphx_view_fetch)
     hipStream_t view_stream = nullptr;
