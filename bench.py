@@ -68,7 +68,8 @@ def main():
                     help="untimed steps before the warm-up (SURVEY 8(d): a second window after 2000 steps = the violent phase, high Id/Iv)")
     ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
-    ap.add_argument("--halo", type=int, default=16, help="ghost halo width in cells (multi-GPU)")
+    ap.add_argument("--halo", type=int, default=16, help="widest ghost halo in cells (multi-GPU); the band in use adapts to the ring budget")
+    ap.add_argument("--fixed-halo", action="store_true", help="always exchange the full --halo band")
     ap.add_argument("--tiles", default="auto", choices=["auto", "strips", "grid"],
                     help="multi-GPU layout: strips along the longer side, or a 2 x N/2 grid (auto: 2x2 on 4 GPUs, strips otherwise; SURVEY 8(e))")
     ap.add_argument("--rebalance-every", type=int, default=16, help="steps between re-partitions of the tile cuts (0 = never)")
@@ -164,7 +165,7 @@ def main():
 
             comm = ThreadComm(ThreadComm.Shared(1), 0)
         tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, layout, halo=args.halo,
-                           rebalance_every=args.rebalance_every)
+                           rebalance_every=args.rebalance_every, adaptive_halo=not args.fixed_halo)
         tiled.setup(pos, None, None, boundary)
         n = n_global // world
 
@@ -283,7 +284,7 @@ def main():
                 "particles_per_gpu": n,
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
-                f"{layout_name}, {args.halo}-cell ghost halo, per step: 1 halo "
+                f"{layout_name}, ghost halo {tiled.halo_now} of <= {args.halo} cells (follows the ring budget), per step: 1 halo "
                 f"exchange (send/recv with {len(tiled.peers)} neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
                 f"{tiled.rebalances} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,

@@ -83,7 +83,7 @@ def test_gpu_tiles_2x2_bit_exact_vs_oracle_tiles():
     from tile_oracle_backend import OracleTileBackend
 
     pos, boundary = dam_break(2.0)
-    kw = dict(halo=10, fixed=(3, 2), rebalance_every=4, layout=lambda: GridLayout.quantile(pos, 2, 2))
+    kw = dict(halo=10, fixed=(3, 2), rebalance_every=4, layout=lambda: GridLayout.quantile(pos, 2, 2), adaptive_halo=True)
     g, _ = run_tiles_threaded(gpu_backend, pos, boundary, 4, None, 150, **kw)
     gl = list(run_tiles_threaded.final_cuts)
     o, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 4, None, 150, **kw)
@@ -91,6 +91,22 @@ def test_gpu_tiles_2x2_bit_exact_vs_oracle_tiles():
     merge_owned(g, len(pos))  # every particle owned exactly once
     for r in range(4):
         assert g[r][2] == o[r][2]  # same number of halo exchanges
+        np.testing.assert_array_equal(g[r][0]["ids"], o[r][0]["ids"])
+        for k in ("pos", "vel", "density", "kappa", "stiffness"):
+            assert_bits_equal(g[r][0][k], o[r][0][k], f"rank {r} {k}")
+
+
+def test_gpu_tiles_adaptive_halo_bit_exact_vs_oracle_tiles():
+    """Adaptive ghost band (shrinks to 8 cells while Id = Iv = 1): same exchanges, same bits as the oracle tiles."""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(1.0)
+    g, _ = run_tiles_threaded(gpu_backend, pos, boundary, 2, 1, 150, halo=16, adaptive_halo=True, rebalance_every=8)
+    hg = [list(h) for h in run_tiles_threaded.halos]
+    o, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 1, 150, halo=16, adaptive_halo=True, rebalance_every=8)
+    assert hg == [list(h) for h in run_tiles_threaded.halos] and min(hg[0]) == 8
+    for r in range(2):
+        assert g[r][2] == o[r][2]
         np.testing.assert_array_equal(g[r][0]["ids"], o[r][0]["ids"])
         for k in ("pos", "vel", "density", "kappa", "stiffness"):
             assert_bits_equal(g[r][0][k], o[r][0][k], f"rank {r} {k}")

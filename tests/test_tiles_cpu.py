@@ -27,20 +27,27 @@ def single_domain(pos, boundary, steps, fixed=(0, 0)):
     return dict(pos=o.positions()[inv], vel=o.velocities()[inv], density=o.densities()[inv]), stats, o.timer_step_ns()
 
 
-def run_tiles_threaded(make_backend, pos, boundary, world, axis, steps, halo=16, fixed=(0, 0), cuts=None, rebalance_every=0, layout=None):
+def run_tiles_threaded(make_backend, pos, boundary, world, axis, steps, halo=16, fixed=(0, 0), cuts=None, rebalance_every=0, layout=None,
+                       adaptive_halo=False):
     """axis/cuts: strips; layout: a factory returning a fresh Layout per rank (e.g. a 2x2 GridLayout)."""
     cuts = quantile_cuts(cell_coord(pos, axis), world) if cuts is None and layout is None else cuts
     shared = ThreadComm.Shared(world)
     out, errs = [None] * world, []
     final_cuts = run_tiles_threaded.final_cuts = [None] * world
+    run_tiles_threaded.halos = [[] for _ in range(world)]
 
     def work(r):
         try:
             lay = layout() if layout is not None else StripLayout(axis, cuts)
-            t = TiledDFSPH(make_backend(r), ThreadComm(shared, r), lay, halo=halo, fixed_iterations=fixed, rebalance_every=rebalance_every)
+            t = TiledDFSPH(make_backend(r), ThreadComm(shared, r), lay, halo=halo, fixed_iterations=fixed, rebalance_every=rebalance_every,
+                           adaptive_halo=adaptive_halo)
+            halos = run_tiles_threaded.halos[r]
             t.setup(pos, None, None, boundary)
             timer = y.TimeManager()
-            stats = [t.step(timer) for _ in range(steps)]
+            stats = []
+            for _ in range(steps):
+                stats.append(t.step(timer))
+                halos.append(t.halo_now)
             out[r] = (t.download_owned(), stats, t.exchanges)
             final_cuts[r] = (list(t.cuts), t.rebalances)
         except BaseException as e:  # noqa: BLE001
@@ -147,6 +154,36 @@ def test_tiles_rebalance_moves_cuts_and_matches_single_domain():
     np.testing.assert_allclose(p, ref["pos"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v, ref["vel"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(d, ref["density"], rtol=1e-5)
+
+
+def test_adaptive_halo_follows_the_ring_budget():
+    """The ghost band in use shrinks to what the solver loops spend (6-8 cells while Id = Iv = 1) and widens again when fixed 3+2
+    iterations need more rings; results stay those of the single-domain run, and no step needs more than its one exchange once the
+    band has adapted."""
+    from tile_oracle_backend import OracleTileBackend
+
+    pos, boundary = dam_break(1.0)
+    steps = 60
+    ref, rstats, _ = single_domain(pos, boundary, steps)
+    outs, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 1, steps, halo=16, adaptive_halo=True)
+    h = run_tiles_threaded.halos
+    assert h[0] == h[1] and h[0][0] <= 16 and min(h[0]) == 8 and h[0][-1] == 8, h[0]
+    assert outs[0][2] == steps + 1, "one exchange per step (+ the set-up one)"
+    for s in range(steps):
+        assert outs[0][1][s]["density_iterations"] == rstats[s]["density_iterations"]
+        assert np.float32(outs[0][1][s]["dt"]) == np.float32(rstats[s]["dt"])
+    p, v, d = merge_owned(outs, len(pos))
+    np.testing.assert_allclose(p, ref["pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v, ref["vel"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d, ref["density"], rtol=1e-5)
+    # long loops: 3 + 2 fixed iterations spend 2*2+1 + 1 + 2*3+1 + 1 = 14 rings -> the band grows to 16 and stays
+    one, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 1, 1, 40, fixed=(3, 2))
+    two, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 1, 40, fixed=(3, 2), halo=16, adaptive_halo=True)
+    assert run_tiles_threaded.halos[0][-1] == 16
+    p1, v1, _ = merge_owned(one, len(pos))
+    p2, v2, _ = merge_owned(two, len(pos))
+    np.testing.assert_allclose(p2, p1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v2, v1, rtol=1e-4, atol=1e-5)
 
 
 def test_grid_layout_geometry():

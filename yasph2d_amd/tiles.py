@@ -389,10 +389,17 @@ class TiledDFSPH:
 
     def __init__(self, backend, comm, layout, cuts=None, halo=16, cap_records=None, max_avg_density_error=np.float32(0.01) / np.float32(100.0),
                  max_density_iterations=200, max_divergence_error=np.float32(0.1) / np.float32(100.0), max_divergence_iterations=400,
-                 fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0, rebalance_every=0):
+                 fixed_iterations=(0, 0), fluid_density=100.0, particle_radius=0.005, h=0.02, grid_min=-100.0, rebalance_every=0,
+                 adaptive_halo=False, min_halo=6):
         if cuts is not None:
             layout = StripLayout(layout, cuts)
-        self.b, self.comm, self.layout, self.halo = backend, comm, layout, int(halo)
+        self.b, self.comm, self.layout = backend, comm, layout
+        # `halo` is the widest ghost band (buffers, tile widths and boundary clipping are sized for it); with adaptive_halo the band
+        # in use follows the ring budget the last step actually needed
+        self.halo_max = int(halo)
+        self.adaptive_halo, self.min_halo = bool(adaptive_halo), min(int(min_halo), int(halo))
+        self.halo_now = self.halo_max
+        self._spent, self._last_div = [], (1, 0)  # ring consumption of the last intervals; (iterations, warm) of the last divergence loop
         self.rank, self.world = comm.rank, comm.world
         if layout.world != self.world:
             raise ValueError("layout and communicator disagree about the number of tiles")
@@ -410,6 +417,21 @@ class TiledDFSPH:
         self._valid = self._kvalid = float("inf")
         self._bufs = {}
 
+    @property
+    def halo(self):
+        return self.halo_max
+
+    def _adapt_halo(self, spent):
+        """Ghost band for the next exchange interval.  `spent` = rings the interval that is ending consumed (divergence loop of
+        the previous step, non-pressure pass and density loop of this one).  The next band is the largest consumption of the last
+        8 intervals plus one more iteration (2 rings), clamped to [min_halo, halo]; if a loop still runs longer, the ring budget
+        triggers an extra exchange — slower, never wrong."""
+        self._spent = (self._spent + [spent])[-8:]
+        new = max(self.min_halo, min(self.halo_max, max(self._spent) + 2))
+        if new != self.halo_now:
+            self.halo_now = new
+            self.b.configure(self.rect, self.halo_now, self.peer_rects)
+
     # historical accessors of the strip form (tests, bench)
     @property
     def axis(self):
@@ -424,15 +446,15 @@ class TiledDFSPH:
         """Own rectangle and the peers (tiles whose rectangle grown by the halo touches it), from the layout."""
         rects = self.layout.rects()
         self.rect = rects[self.rank]
-        self.peers = [k for k in range(self.world) if k != self.rank and rects_touch(self.rect, rects[k], self.halo)]
+        self.peers = [k for k in range(self.world) if k != self.rank and rects_touch(self.rect, rects[k], self.halo_max)]
         if len(self.peers) > 8:
             raise ValueError("a tile touches more than 8 others: tiles are too small for this halo")
         for k in [self.rank] + self.peers:  # interior extents must hold two halo widths (ghosts come from direct neighbours only)
             x0, x1, y0, y1 = rects[k]
-            if (x0 > 0 and x1 < 65536 and x1 - x0 < 2 * self.halo) or (y0 > 0 and y1 < 65536 and y1 - y0 < 2 * self.halo):
+            if (x0 > 0 and x1 < 65536 and x1 - x0 < 2 * self.halo_max) or (y0 > 0 and y1 < 65536 and y1 - y0 < 2 * self.halo_max):
                 raise ValueError("tiles must be at least two halo widths wide")
         self.peer_rects = [rects[k] for k in self.peers]
-        self.b.configure(self.rect, self.halo, self.peer_rects)
+        self.b.configure(self.rect, self.halo_now, self.peer_rects)
 
     def _buffers(self):
         need = [k for k in self.peers if k not in self._bufs]
@@ -459,8 +481,8 @@ class TiledDFSPH:
             for a in range(self.world):
                 ma = in_rect(cx, cy, rects[a])
                 for b in range(self.world):
-                    if a != b and rects_touch(rects[a], rects[b], self.halo):
-                        near = max(near, int((ma & in_rect(cx, cy, rects[b], self.halo)).sum()))
+                    if a != b and rects_touch(rects[a], rects[b], self.halo_max):
+                        near = max(near, int((ma & in_rect(cx, cy, rects[b], self.halo_max)).sum()))
             self.cap = max(1024, int(near * 1.5) + 1024)
         self.b.reserve(int(n_own * 1.25) + 2 * max(2, len(self.peers)) * self.cap + 4096)
         span = lambda c: max(1, int(c.max()) - int(c.min()) + 1) if len(c) else 1  # noqa: E731
@@ -476,7 +498,7 @@ class TiledDFSPH:
         self.refresh()  # initial ghosts + the warm-up block (dfsph.rs:419-428): re-grid, densities, alpha
 
     def _clip_boundary(self):
-        m = self.halo + 2 + (self.boundary_margin if self.rebalance_every else 0)
+        m = self.halo_max + 2 + (self.boundary_margin if self.rebalance_every else 0)
         self._clip_rect = self.rect
         keep = in_rect(self.boundary_cells[0], self.boundary_cells[1], self.rect, m)
         self.b.set_boundary(self.boundary[keep])
@@ -493,7 +515,9 @@ class TiledDFSPH:
         """Move the cuts towards equal owned counts; takes effect in the refresh() that follows (the pack/retire/apply rules are
         purely geometric, so particles of the band that changes owner travel as ordinary migrants)."""
         counts = self._allgather(self.n_owned_local)
-        if not self.layout.rebalance(counts, self.halo, self.columns, max(1, self.halo // 4)):
+        # a cut moves by at most halo/4 cells and never further than the narrowest ghost band in use: the band that changes owner is
+        # then still inside the old owner's ghost band (it keeps those particles as ghosts, k_tile_pack)
+        if not self.layout.rebalance(counts, self.halo_max, self.columns, max(1, min(self.halo_max // 4, self.min_halo))):
             return False
         self._place()
         if self.boundary is not None and max(abs(a - b) for a, b in zip(self.rect, self._clip_rect)) > self.boundary_margin // 2:
@@ -502,17 +526,27 @@ class TiledDFSPH:
         return True
 
     # ---- halo ---------------------------------------------------------------------------------------------------------------
+    def _cap_now(self):
+        """Records per peer buffer for the band in use: the set-up estimate for the widest band, scaled (cuts may also have moved by
+        up to halo/4 cells, hence the +4); every rank computes the same number, sender and receiver agree on the layout."""
+        if self.halo_now >= self.halo_max:
+            return self.cap
+        return min(self.cap, max(1024, -(-self.cap * (self.halo_now + 4) // (self.halo_max + 4))))
+
     def refresh(self):
         """Halo exchange (migration + fresh ghosts) followed by the re-grid of the local set."""
         sends, recvs = self._buffers()
-        self.b.pack(sends, self.cap)
+        cap = self._cap_now()
+        nbytes = (1 + cap) * HALO_RECORD_BYTES
+        sends, recvs = [t[:nbytes] for t in sends], [t[:nbytes] for t in recvs]  # only the part the band in use can fill travels
+        self.b.pack(sends, cap)
         ordered = getattr(self.b, "stream", None) is not None  # kernels and communication share one stream: no host sync
         with (self.b.stream_context() if ordered else contextlib.nullcontext()):
             self.comm.exchange(self.peers, sends, recvs, stream_ordered=ordered)
-        self.b.apply(recvs, self.cap)
+        self.b.apply(recvs, cap)
         self.n_local = self.b.regrid()
         self.exchanges += 1
-        full = float("inf") if self.world == 1 else float(self.halo)
+        full = float("inf") if self.world == 1 else float(self.halo_now)
         self._valid = self._kvalid = full          # rings (cells from the owned region) in which v* / kappa are exact
         self._avalid = full - 1                    # ... density and alpha (one traversal after the exchange)
 
@@ -583,8 +617,13 @@ class TiledDFSPH:
         self._steps += 1
         if self.rebalance_every and self.world > 1 and self._steps % self.rebalance_every == 0:
             self.rebalance()
+        if self.adaptive_halo and self.world > 1:
+            # rings of the interval that ends here: divergence loop of the previous step, non-pressure pass, this density loop, and
+            # the one-ring offset of density/alpha (computed one traversal after the exchange)
+            self._adapt_halo(self._last_div[1] + 2 * self._last_div[0] + 1 + wd + 2 * Id + 1)
         self.refresh()                                                      # migration + ghosts, dfsph.rs:512-518
         Iv, avg_v, wv = self._loop(True, dt)                                # dfsph.rs:521
+        self._last_div = (Iv, wv)
         return dict(density_iterations=Id, divergence_iterations=Iv, warmstart_density=wd, warmstart_divergence=wv, avg_density_error=avg_d,
                     avg_divergence=avg_v, dt_prev=dt_prev, dt=dt, vmax=vmax, dt_ns=dt_ns, n_local=self.n_local, n_global=self.n_owned_global)
 
