@@ -161,18 +161,31 @@ __device__ __forceinline__ bool arrive_is_last(DevScalars* scal) {  // call from
     const uint32_t t2 = __hip_atomic_fetch_add(&scal->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return t2 == nstripes - 1;
 }
-__device__ __forceinline__ void publish_common(DevScalars* scal, Mailbox* mb, uint32_t seq) {  // one thread of the last block
-    unsigned long long nb = 0;
-    for (uint32_t k = 0; k < STRIPES; ++k) nb += __hip_atomic_load(&scal->stripe[k].nb_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long ow = 0;
-    for (uint32_t k = 0; k < STRIPES; ++k) ow += __hip_atomic_load(&scal->stripe[k].owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mb->owned_cum = ow;
-    mb->sort_total = __hip_atomic_load(&scal->sort_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mb->nb_entries = nb;
-    mb->flags = __hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// Called by ALL threads of the last workgroup (>= 64 threads); thread 0 has already written the kernel-specific mailbox fields.
+// The striped counters are read by one lane each instead of 64 dependent loads of a single thread: this sits on the critical
+// path between the end of a reduction kernel and the host seeing its result.
+__device__ __forceinline__ void publish_common(DevScalars* scal, Mailbox* mb, uint32_t seq) {
+    static_assert(STRIPES <= 64, "one lane per stripe");
+    if (threadIdx.x >= 64) return;
+    unsigned long long nb = 0, ow = 0;
+    if (threadIdx.x < STRIPES) {
+        nb = __hip_atomic_load(&scal->stripe[threadIdx.x].nb_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ow = __hip_atomic_load(&scal->stripe[threadIdx.x].owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nb += __shfl_down(nb, d, 64);
+        ow += __shfl_down(ow, d, 64);
+    }
+    if (threadIdx.x == 0) {
+        mb->owned_cum = ow;
+        mb->sort_total = __hip_atomic_load(&scal->sort_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mb->nb_entries = nb;
+        mb->flags = __hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&scal->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // block-wide f64 sum in a fixed tree (lane -> wave -> 4 waves); result valid in thread 0
@@ -1057,8 +1070,8 @@ __device__ __forceinline__ void reduce_publish_vmax(float vsq, uint32_t* __restr
                 mb->dt_ns = ns;
                 mb->dt_bits = __float_as_uint(dt_new);
             }
-            publish_common(scal, mb, seq);
         }
+        publish_common(scal, mb, seq);
     }
 }
 
@@ -1244,10 +1257,8 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
         for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256)
             s += __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         s = block_sum_f64(s);
-        if (threadIdx.x == 0) {
-            mb->err_sum = s;
-            publish_common(scal, mb, seq);
-        }
+        if (threadIdx.x == 0) mb->err_sum = s;
+        publish_common(scal, mb, seq);
     }
 }
 
@@ -1353,19 +1364,26 @@ __global__ __launch_bounds__(256) void k_view_pack(const float4* __restrict__ PV
     out[3 * (size_t)k + 2] = sqrtf(pv.z * pv.z + pv.w * pv.w);  // cgmath magnitude()
 }
 // publish the sticky flags / neighbour-entry count outside a solver step (sphx_update_neighborhood)
-__global__ void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {
-    unsigned long long nb = 0;
-    unsigned long long ow = 0;
-    for (uint32_t k = 0; k < STRIPES; ++k) {
-        nb += scal->stripe[k].nb_entries;
-        ow += scal->stripe[k].owned;
+__global__ __launch_bounds__(64) void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {  // one wavefront: stripes in parallel
+    static_assert(STRIPES <= 64, "one lane per stripe");
+    unsigned long long nb = 0, ow = 0;
+    if (threadIdx.x < STRIPES) {
+        nb = scal->stripe[threadIdx.x].nb_entries;
+        ow = scal->stripe[threadIdx.x].owned;
     }
-    mb->nb_entries = nb;
-    mb->owned_cum = ow;
-    mb->sort_total = scal->sort_total;
-    mb->flags = scal->flags;
-    __threadfence_system();
-    __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nb += __shfl_down(nb, d, 64);
+        ow += __shfl_down(ow, d, 64);
+    }
+    if (threadIdx.x == 0) {
+        mb->nb_entries = nb;
+        mb->owned_cum = ow;
+        mb->sort_total = scal->sort_total;
+        mb->flags = scal->flags;
+        __threadfence_system();
+        __hip_atomic_store((uint32_t*)&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace sphx
