@@ -686,8 +686,8 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
 
 // Fine-table slots of the 3x3 cell box around (cx, cy), ascending.  The fine table is in global Morton order (blocks ranked in
 // Morton order, cells inside a block by the low 12 bits of their code), so sorting the SLOTS sorts the cells by Morton code —
-// no 32-bit codes, no de-interleaving of block coordinates.  Cells outside the u16 range or in blocks the directory does not
-// cover get EMPTY and sort to the end.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit positions.
+// no 32-bit codes, no de-interleaving of block coordinates.  Cells in blocks the directory does not cover get EMPTY and sort to
+// the end.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit positions.
 __device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2,4,6,8,10
     v &= 63u;
     v = (v | (v << 4)) & 0x30Fu;
@@ -696,15 +696,19 @@ __device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2
     return v;
 }
 __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9]) {
+    // Cells on the rim of the u16 domain: the reference computes the box corners as u16 `pos.x - 1` / `pos.x + 1`
+    // (neighborhood_search.rs:193-194), which wrap in a release build (a debug build panics): the x- or y-range of the box is then
+    // empty and the particle gets NO neighbours, dynamic or static.  grid_min = -100 keeps real scenes 5000 cells away from the
+    // rim; the rule is restated for parity (tests/test_gpu_random_scenes.py puts a sheet of fluid into the corner).
+    const bool rim = cx - 1u >= 65534u || cy - 1u >= 65534u;
     uint32_t lx[3], ly[3], bx[3], by[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
         lx[d] = spread6(x);
         ly[d] = spread6(y) << 1;
-        // x = 65535 and the wrapped -1 are outside the reference's u16 cell range: an out-of-range block index makes them EMPTY
-        bx[d] = x < 65535u ? (x >> BLOCK_SHIFT) - g.bx0 : 0xFFFFFFFFu;
-        by[d] = y < 65535u ? (y >> BLOCK_SHIFT) - g.by0 : 0xFFFFFFFFu;
+        bx[d] = (x >> BLOCK_SHIFT) - g.bx0;
+        by[d] = (y >> BLOCK_SHIFT) - g.by0;
     }
     bool any = false;
 #pragma unroll
@@ -712,7 +716,7 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             uint32_t off = EMPTY;
-            if (bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
+            if (!rim && bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
             any |= off != EMPTY;
             slot[dy * 3 + dx] = off == EMPTY ? EMPTY : off + (ly[dy] | lx[dx]);
         }
