@@ -123,3 +123,31 @@ def test_random_scene(seed, span):
     assert_bits_equal(ss["kappa"], o.kappa(), "kappa")
     assert_bits_equal(ss["stiffness"], o.stiffness(), "stiffness")
     assert_same_neighbors(ctx.download_neighbors(), o.neighbors())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 6, 7, 8])
+def test_random_scene_wcsph(seed):
+    """The same clouds through the WCSPH step (adaptive timer, cfl 0.2): leap frog, Poly6 densities, Tait/Spiky/XSPH/boundary forces."""
+    pos, vel, boundary = scene(seed)
+    ctx = y.SphxContext()
+    o = Oracle()
+    timer = y.TimeManager(cfl_factor=0.2)
+    o.timer_adaptive(timer.timestep_max_ns, timer.timestep_min_ns, 0.2)
+    if len(boundary):
+        ctx.set_boundary(boundary)
+        o.set_boundary(boundary)
+    ctx.upload(pos, vel)
+    o.set_particles(pos, vel)
+    diam = np.float32(0.01)
+    for s in range(25):
+        vmax = ctx.wcsph_step_begin(timer.simulation_step())
+        dt_ns = timer.update_simulation_step(diam, vmax)
+        ctx.wcsph_step_finish(y.duration_as_secs_f32(dt_ns))
+        so = o.wcsph_step()
+        assert dt_ns == o.timer_step_ns(), (seed, s)
+        assert np.float32(vmax) == np.float32(so["vmax"]), (seed, s)
+    d = ctx.download()
+    np.testing.assert_array_equal(d["ids"], o.ids())
+    assert_bits_equal(d["pos"], o.positions(), f"seed {seed} positions")
+    assert_bits_equal(d["vel"], o.velocities(), f"seed {seed} velocities")
+    assert_bits_equal(d["density"], o.densities(), f"seed {seed} densities")

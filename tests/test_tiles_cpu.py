@@ -349,3 +349,42 @@ def test_shm_allreduce_four_processes():
             want = (sa, sb)
         for r in range(world):
             assert got[r][it] == want
+
+
+def test_rebalance_cuts_invariants_random():
+    """Whatever the loads: cuts stay strictly increasing with the outer ones fixed, no cut moves further than max_shift, interior
+    tiles keep two halo widths (+2), and the function is a pure function of its inputs."""
+    from yasph2d_amd.tiles import rebalance_cuts
+
+    rng = np.random.default_rng(11)
+    for _ in range(2000):
+        W = int(rng.integers(2, 9))
+        halo = int(rng.integers(2, 17))
+        widths = rng.integers(2 * halo + 2, 400, W - 2) if W > 2 else np.zeros(0, int)
+        first = int(rng.integers(1000, 30000))
+        cuts = [0, first] + [int(first + w) for w in np.cumsum(widths)] + [65536]
+        counts = [float(c) for c in rng.integers(0, 100000, W)]
+        max_shift = int(rng.integers(1, halo + 1))
+        new = rebalance_cuts(cuts, counts, halo, float(rng.uniform(1, 500)), max_shift)
+        assert new[0] == 0 and new[-1] == 65536 and len(new) == len(cuts)
+        assert all(b > a for a, b in zip(new, new[1:]))
+        assert all(abs(a - b) <= max_shift for a, b in zip(new, cuts))
+        assert all(new[r + 1] - new[r] >= 2 * halo + 2 for r in range(1, W - 1))
+
+
+def test_grid_layout_partitions_random_clouds():
+    from yasph2d_amd.tiles import in_rect
+
+    rng = np.random.default_rng(12)
+    for _ in range(20):
+        n = int(rng.integers(2000, 20000))
+        pos = (rng.normal(0, 1, (n, 2)) * rng.uniform(0.2, 3.0, 2) + rng.uniform(-5, 5, 2)).astype(np.float32)
+        nx, ny = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        lay = GridLayout.quantile(pos, nx, ny)
+        rects = lay.rects()
+        cx, cy = cell_coord(pos, 0), cell_coord(pos, 1)
+        owner = sum(in_rect(cx, cy, r).astype(int) for r in rects)
+        assert (owner == 1).all()
+        # the rectangles tile the whole domain
+        area = sum((r[1] - r[0]) * (r[3] - r[2]) for r in rects)
+        assert area == 65536 * 65536
