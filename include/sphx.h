@@ -43,7 +43,9 @@ enum {
     SPHX_FLAG_NEIGHBOR_CAP = 1u,            /* "particle has too many neighbors" (neighborhood_search.rs:361,376) */
     SPHX_FLAG_DENSITY_ITER_CAP = 2u,        /* "Density error correction canceled" (dfsph.rs:236-245) */
     SPHX_FLAG_DIVERGENCE_ITER_CAP = 4u,     /* "Divergence error correction canceled" (dfsph.rs:391-400) */
-    SPHX_FLAG_WARMUP = 8u                   /* this step ran the warm-up block (dfsph.rs:419-428) */
+    SPHX_FLAG_WARMUP = 8u,                  /* this step ran the warm-up block (dfsph.rs:419-428) */
+    SPHX_FLAG_STRAY_PARTICLES = 16u         /* a particle moved more than a 64-cell block beyond the covered region in one step (a blow-up);
+                                               it is kept, without neighbours, and the cell directory is re-covered before the next build */
 };
 
 /* kernel kinds for sphx_update_densities (src/sph/smoothing_kernel/) */

@@ -190,3 +190,38 @@ def test_viewer_feed_strided_async_download():
         if got is not None:
             break
     assert got is not None and got.shape[1] == 3
+
+
+def test_particles_that_outrun_the_cell_directory_are_kept():
+    """A blob moving 150 cells per step (3000 m/s at a fixed 1 ms step) leaves the covered 64x64-cell blocks in one step.  The
+    reference has no such table and simply carries on; so does the device now: nothing is lost, SPHX_FLAG_STRAY_PARTICLES is
+    reported, the directory is re-covered, and the blob arrives where ballistic motion takes it."""
+    side = 30
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(np.float32)
+    pos = (np.float32(1.0) + g * np.float32(0.0111)).astype(np.float32)
+    slow = (np.float32(-3.0) + g * np.float32(0.0111)).astype(np.float32)  # a second blob that stays put
+    allpos = np.concatenate([pos, slow])
+    vel = np.concatenate([np.tile(np.array([[3000.0, 0.0]], np.float32), (len(pos), 1)), np.zeros_like(slow)])
+    p = y.default_params()
+    p.gravity[0], p.gravity[1] = 0.0, 0.0
+    ctx = y.SphxContext(p)
+    ctx.upload(allpos, vel)
+    timer = y.TimeManager(fixed_ns=1_000_000)
+    diam = np.float32(0.01)
+    flagged = 0
+    for _ in range(30):
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+        st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+        flagged += bool(st["flags"] & y.FLAG_STRAY_PARTICLES)
+    assert flagged >= 1
+    d = ctx.download()
+    assert sorted(d["ids"].tolist()) == list(range(len(allpos)))
+    assert np.isfinite(d["pos"]).all()
+    fast = d["ids"] < len(pos)
+    travelled = d["pos"][fast, 0].mean() - pos[:, 0].mean()
+    assert abs(travelled - 3000.0 * 30e-3) < 0.05 * 90.0  # ~90 m, ballistic
+    assert np.ptp(d["pos"][fast, 0]) < 2.0 and np.ptp(d["pos"][fast, 1]) < 2.0  # still a blob
+    assert abs(d["pos"][~fast, 0].mean() - slow[:, 0].mean()) < 0.1  # the other blob stayed where it was
+    # both blobs have their neighbours again
+    counts, _, _ = ctx.download_neighbors()
+    assert counts[:, 1].mean() > 5

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_NEIGHBOR_CAP, FLAG_WARMUP, KERNEL_POLY6,  # noqa: F401
+from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_NEIGHBOR_CAP, FLAG_STRAY_PARTICLES, FLAG_WARMUP, KERNEL_POLY6,  # noqa: F401
                    KERNEL_SPIKY, KERNEL_WENDLAND_C2, SphxError, SphxKernelTime, SphxParams, SphxStepStats)
 
 __all__ = ["SphxContext", "FluidParticleWorld", "TimeManager", "DFSPHSolver", "default_params", "duration_from_secs_f32",

@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (sphx.h)
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY, ERR_NONFINITE, ERR_NEIGHBOR_PANIC, ERR_CAPACITY, ERR_OUT_OF_DOMAIN = range(9)
-FLAG_NEIGHBOR_CAP, FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_WARMUP = 1, 2, 4, 8
+FLAG_NEIGHBOR_CAP, FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_WARMUP, FLAG_STRAY_PARTICLES = 1, 2, 4, 8, 16
 KERNEL_WENDLAND_C2, KERNEL_POLY6, KERNEL_SPIKY = 0, 1, 2
 
 

@@ -24,7 +24,7 @@ constexpr uint32_t WIN_HALO = 256;      // neighbour build: positions of [block_
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
 constexpr uint32_t MAX_TILE_PEERS = 8;  // a rectangle has at most 8 neighbours (4 edges + 4 corners) in a regular tiling
@@ -165,6 +165,9 @@ struct sphx_ctx {
     bool have_fluid_bbox = false;
     uint32_t fb[4] = {0, 0, 0, 0};  // fluid cell bbox at upload (x0,y0,x1,y1)
     bool need_expand = false;       // a particle reached the outer ring of the dynamic directory: grow it before the next build
+    bool need_recover = false;      // a particle outran the directory (DF_STRAY): re-cover the true bounding box before the next build
+    uint32_t recover_streak = 0;    // builds that still re-cover predictively after strays were seen
+    uint32_t recover_cooldown = 0;  // builds to wait before the next re-cover attempt when the box is too large to cover
     std::vector<float> h_boundary;  // host copy of the boundary (caller order): the static directory is built on the host
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;

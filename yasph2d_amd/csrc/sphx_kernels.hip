@@ -344,10 +344,21 @@ __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV
         }
         uint32_t cx, cy;
         cell_of(K, p, cx, cy);
-        const uint32_t code = morton2(cx, cy);
         const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
-        idx = dropped ? EMPTY : grid_slot(g, cx, cy, code);
         uint32_t f = 0;
+        if (ring && !dropped) {
+            // A particle that outran the covered rectangle (more than a 64-cell block in one step: a blow-up, or a huge fixed dt)
+            // is not lost: it is sorted into the nearest covered cell.  Its own 3x3 box lies outside the directory, so it has no
+            // neighbours (as far from everything as it is, it would have none anyway) until the host has re-covered the domain.
+            const uint32_t x0 = g.bx0 << BLOCK_SHIFT, x1 = ((g.bx0 + g.nbx) << BLOCK_SHIFT) - 1u;
+            const uint32_t y0 = g.by0 << BLOCK_SHIFT, y1 = ((g.by0 + g.nby) << BLOCK_SHIFT) - 1u;
+            const uint32_t sx = min(max(cx, x0), x1), sy = min(max(cy, y0), y1);
+            if (sx != cx || sy != cy) f |= DF_STRAY;
+            cx = sx;
+            cy = sy;
+        }
+        const uint32_t code = morton2(cx, cy);
+        idx = dropped ? EMPTY : grid_slot(g, cx, cy, code);
         if (idx == EMPTY && !dropped) f |= DF_OUT_OF_DOMAIN;
         if (ring) {  // dynamic grid: warn the host long before a particle can leave the covered rectangle
             const uint32_t bx = (cx >> BLOCK_SHIFT) - g.bx0, by = (cy >> BLOCK_SHIFT) - g.by0;
