@@ -225,3 +225,18 @@ def test_particles_that_outrun_the_cell_directory_are_kept():
     # both blobs have their neighbours again
     counts, _, _ = ctx.download_neighbors()
     assert counts[:, 1].mean() > 5
+
+
+def test_far_apart_pools_use_a_sparse_directory():
+    """Two pools 1.2 km apart (60 000 cells): a dense rectangle of 64x64-cell blocks over their bounding box would need > 3 G table
+    entries; the sparse directory covers the two pools and their fringes only.  Results equal the oracle's."""
+    side = 40
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(np.float32)
+    a = (np.array([-90.0, -90.0], np.float32) + g * np.float32(0.0111)).astype(np.float32)
+    b = (np.array([1100.0, 1100.0], np.float32) + g * np.float32(0.0111)).astype(np.float32)
+    pos = np.concatenate([a, b])
+    ctx, o = pair(pos, None)
+    timer = y.TimeManager()
+    for _ in range(30):
+        step_both(ctx, o, timer)
+    compare_state(ctx, o, "two pools")

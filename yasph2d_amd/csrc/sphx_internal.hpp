@@ -24,6 +24,7 @@ constexpr uint32_t WIN_HALO = 256;      // neighbour build: positions of [block_
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
+constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered block on the fringe of the fluid (offsets stay < 2^31)
 enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
@@ -113,6 +114,7 @@ struct Grid {
     uint32_t* hist = nullptr;  // all-zero between builds; receives the next build's per-cell histogram
     uint32_t fine_cap = 0;     // entries allocated in fine and hist
     uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
+    std::vector<uint8_t> cover;  // dynamic grid, host side: 0 uncovered / 1 interior / 2 fringe per block of the rectangle
     uint32_t len() const { return nblk * BLOCK_CELLS; }
     GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
 };

@@ -52,12 +52,16 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t x) {  // morton.rs:57-6
     x = (x ^ (x >> 8)) & 0x0000ffffu;
     return x;
 }
-// index of cell (x,y) (Morton code `code`) in the fine table, or EMPTY if its 64x64 block is not in the directory
-__device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uint32_t y, uint32_t code) {
+// directory entry of the 64x64 block of cell (x,y): table offset | DIR_FRINGE, or EMPTY if the block is not covered
+__device__ __forceinline__ uint32_t dir_entry(const GridView& g, uint32_t x, uint32_t y) {
     const uint32_t bx = (x >> BLOCK_SHIFT) - g.bx0, by = (y >> BLOCK_SHIFT) - g.by0;
     if (bx >= g.nbx || by >= g.nby) return EMPTY;
-    const uint32_t off = g.dir[by * g.nbx + bx];
-    return off == EMPTY ? EMPTY : off + (code & (BLOCK_CELLS - 1u));
+    return g.dir[by * g.nbx + bx];
+}
+// index of cell (x,y) (Morton code `code`) in the fine table, or EMPTY if its 64x64 block is not in the directory
+__device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uint32_t y, uint32_t code) {
+    const uint32_t off = dir_entry(g, x, y);
+    return off == EMPTY ? EMPTY : (off & ~DIR_FRINGE) + (code & (BLOCK_CELLS - 1u));
 }
 
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
@@ -346,23 +350,23 @@ __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV
         cell_of(K, p, cx, cy);
         const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
         uint32_t f = 0;
-        if (ring && !dropped) {
-            // A particle that outran the covered rectangle (more than a 64-cell block in one step: a blow-up, or a huge fixed dt)
-            // is not lost: it is sorted into the nearest covered cell.  Its own 3x3 box lies outside the directory, so it has no
-            // neighbours (as far from everything as it is, it would have none anyway) until the host has re-covered the domain.
-            const uint32_t x0 = g.bx0 << BLOCK_SHIFT, x1 = ((g.bx0 + g.nbx) << BLOCK_SHIFT) - 1u;
-            const uint32_t y0 = g.by0 << BLOCK_SHIFT, y1 = ((g.by0 + g.nby) << BLOCK_SHIFT) - 1u;
-            const uint32_t sx = min(max(cx, x0), x1), sy = min(max(cy, y0), y1);
-            if (sx != cx || sy != cy) f |= DF_STRAY;
-            cx = sx;
-            cy = sy;
-        }
         const uint32_t code = morton2(cx, cy);
-        idx = dropped ? EMPTY : grid_slot(g, cx, cy, code);
-        if (idx == EMPTY && !dropped) f |= DF_OUT_OF_DOMAIN;
-        if (ring) {  // dynamic grid: warn the host long before a particle can leave the covered rectangle
-            const uint32_t bx = (cx >> BLOCK_SHIFT) - g.bx0, by = (cy >> BLOCK_SHIFT) - g.by0;
-            if (!dropped && (bx == 0 || by == 0 || bx + 1 >= g.nbx || by + 1 >= g.nby)) f |= DF_NEAR_EDGE;
+        const uint32_t entry = dropped ? EMPTY : dir_entry(g, cx, cy);
+        idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FRINGE) + (code & (BLOCK_CELLS - 1u));
+        if (!dropped) {
+            if (entry == EMPTY) {
+                if (ring) {
+                    // A particle on uncovered ground (it outran the fringe — more than a 64-cell block in one step: a blow-up, or a huge
+                    // fixed dt) is not lost: it is parked in the table's first cell.  Its own 3x3 box is not in the directory, so it has
+                    // no neighbours (as far from everything as it is, it would have none anyway) until the host has re-covered the domain.
+                    idx = 0;
+                    f |= DF_STRAY;
+                } else {
+                    f |= DF_OUT_OF_DOMAIN;  // the static grid is built from exact occupancy: cannot happen
+                }
+            } else if (entry & DIR_FRINGE) {
+                f |= DF_NEAR_EDGE;  // dynamic grid: warn the host long before a particle can reach uncovered ground
+            }
         }
         if (f && (__hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&scal->flags, f);
         cidx[i] = idx;
@@ -729,7 +733,7 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
             uint32_t off = EMPTY;
             if (!rim && bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
             any |= off != EMPTY;
-            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : off + (ly[dy] | lx[dx]);
+            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : (off & ~DIR_FRINGE) + (ly[dy] | lx[dx]);
         }
     sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
     return any;
