@@ -12,7 +12,8 @@
  *     Duration::from_secs_f32 on non-finite input) become error codes; sphx_last_error() gives the text.
  *   - the caller owns every host pointer (borrowed for the duration of the call); the library owns all device memory.
  *   - one context = one caller thread at a time (mirrors `&mut self` of Solver::simulation_step, solver/mod.rs:17).
- *   - all device work runs on one HIP stream owned by the context; calls that return host data synchronise it.
+ *   - all device work runs on one HIP stream — the context's own, or the caller's (sphx_set_stream); calls that return host data
+ *     synchronise it.  The only exception is the viewer feed's device-to-host copy, which has a stream of its own.
  */
 #ifndef SPHX_H
 #define SPHX_H
