@@ -2,7 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <functional>
