@@ -36,6 +36,7 @@ def test_harness_matches_python_driver(solver, extra):
     timer = y.TimeManager(cfl_factor=0.2) if solver == "wcsph" else y.TimeManager()
     diam = np.float32(0.01)
     for _ in range(steps):
+        timer.on_step_started()  # the harness advances the clock like simulation_frame_loop does (timemanager.rs:244-247)
         if solver == "wcsph":
             vmax = ctx.wcsph_step_begin(timer.simulation_step())
             ctx.wcsph_step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
@@ -48,6 +49,7 @@ def test_harness_matches_python_driver(solver, extra):
     by_id[d["ids"], 2:] = d["vel"]
     assert res["particles"] == len(d["ids"]) and res["steps"] == steps
     assert res["timer_step_ns"] == timer.simulation_step_ns()
+    assert res["simulated_ns"] == timer.total_simulated_ns  # also catches a harness built against a stale sphx_host.hpp
     assert int(res["state_fnv1a"], 16) == fnv1a(by_id.tobytes())
     assert res["particle_steps_per_s"] > 0
 
