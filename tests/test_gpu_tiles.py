@@ -132,3 +132,25 @@ def test_gpu_tiles_random_clouds_bit_exact_vs_oracle_tiles(seed, nx, ny):
         np.testing.assert_array_equal(g[r][0]["ids"], o[r][0]["ids"])
         for k in ("pos", "vel", "density", "kappa", "stiffness"):
             assert_bits_equal(g[r][0][k], o[r][0][k], f"rank {r} {k}")
+
+
+def test_gpu_tiles_are_deterministic_run_to_run():
+    """The same tiled run 25 times: exchanges, iteration counts, local counts and the final bits never vary.  (This is the probe
+    that exposed a null-stream memset racing with the next build's histogram — one run in ~30 lost a few ghosts.)"""
+    from test_gpu_random_scenes import scene
+    from test_tiles_cpu import GridLayout
+
+    pos, _, boundary = scene(7)
+    kw = dict(halo=8, rebalance_every=4, adaptive_halo=True, layout=lambda: GridLayout.quantile(pos, 2, 2))
+
+    def summary(out):
+        return [(o[2], [(s["density_iterations"], s["divergence_iterations"], s["n_local"], s["n_global"]) for s in o[1]],
+                 o[0]["pos"].tobytes(), o[0]["vel"].tobytes()) for o in out]
+
+    ref = None
+    for _ in range(25):
+        out, _ = run_tiles_threaded(gpu_backend, pos, boundary, 4, None, 40, **kw)
+        s = summary(out)
+        if ref is None:
+            ref = s
+        assert s == ref
