@@ -1371,6 +1371,9 @@ __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos,
     cell_of(K, pos[i], cx, cy);
     key[i] = morton2(cx, cy);
 }
+// the host has consumed these sticky flag bits: clear exactly them (a plain memset would also wipe bits a kernel queued in between
+// has raised since they were published — e.g. the neighbour build's cap / panic bits behind the tile re-grid's early publish)
+__global__ void k_clear_flags(DevScalars* scal, uint32_t mask) { atomicAnd(&scal->flags, ~mask); }
 // viewer feed (main.rs:239-258 draws every particle at its position, coloured by |v|): every stride-th
 // particle as {x, y, |v|}
 __global__ __launch_bounds__(256) void k_view_pack(const float4* __restrict__ PV, uint32_t n, uint32_t stride, float* __restrict__ out) {
