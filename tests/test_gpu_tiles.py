@@ -154,3 +154,22 @@ def test_gpu_tiles_are_deterministic_run_to_run():
         if ref is None:
             ref = s
         assert s == ref
+
+
+def test_gpu_tile_that_owns_nothing():
+    """A tile whose rectangle holds no fluid at all (all particles on the other side of the cut): it reports 0 owned particles to
+    the residual average every iteration — not a stale count — and the other tile reproduces the oracle tiles bit for bit."""
+    from tile_oracle_backend import OracleTileBackend
+    from yasph2d_amd.tiles import cell_coord
+
+    pos, boundary = dam_break(1.0)
+    c = cell_coord(pos, 0)
+    cuts = [0, int(c.max()) + 40, 65536]  # everything is left of the cut, 40 cells away from it
+    g, _ = run_tiles_threaded(gpu_backend, pos, boundary, 2, 0, 60, halo=8, cuts=cuts)
+    o, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 0, 60, halo=8, cuts=cuts)
+    assert len(g[1][0]["ids"]) == 0 and len(g[0][0]["ids"]) == len(pos)
+    for a, b in zip(g[0][1], o[0][1]):
+        for k in ("density_iterations", "divergence_iterations", "dt_ns", "n_global"):
+            assert a[k] == b[k]
+    assert_bits_equal(g[0][0]["pos"], o[0][0]["pos"], "positions")
+    assert_bits_equal(g[0][0]["vel"], o[0][0]["vel"], "velocities")

@@ -205,7 +205,8 @@ struct sphx_ctx {
     sphx::Mailbox* mbox_dev = nullptr;  // its device address
     uint32_t seq = 0;
     unsigned long long nb_cum = 0, nb_last = 0;  // cumulative neighbour-entry counter seen so far / entries of the last build
-    unsigned long long owned_cum = 0, owned_last = 0;
+    unsigned long long owned_cum = 0, owned_last = 0, owned_base = 0;  // cumulative owned counter (host copy), last re-grid's count
+    bool owned_dirty = false;  // a tile re-grid ran: the next iteration's publish carries its owned count
     // tile mode (multi-GPU spatial decomposition)
     bool tile_mode = false;
     uint32_t tile_halo = 0;
