@@ -171,3 +171,33 @@ def test_exploding_cloud_is_survived():
     d = ctx.download()
     assert sorted(d["ids"].tolist()) == list(range(len(pos)))
     assert np.isfinite(d["pos"]).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 5, 8, 10, 13])
+def test_random_scene_long_adaptive(seed):
+    """The same clouds with the adaptive timer and adaptive iteration counts for 400 steps: the blobs fall onto their floor segments
+    (or into the void), warm starts and multi-iteration loops occur, the cell directory follows the motion."""
+    pos, vel, boundary = scene(seed)
+    ctx, o = y.SphxContext(), Oracle()
+    if len(boundary):
+        ctx.set_boundary(boundary)
+        o.set_boundary(boundary)
+    ctx.upload(pos, vel)
+    o.set_particles(pos, vel)
+    timer = y.TimeManager()
+    diam = np.float32(0.01)
+    for s in range(400):
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(diam))
+        dt_ns = timer.update_simulation_step(diam, vmax)
+        st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns(), (seed, s)
+        for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence", "neighbor_entries"):
+            assert st[k] == so[k], (seed, s, k, st[k], so[k])
+    d = ctx.download()
+    np.testing.assert_array_equal(d["ids"], o.ids())
+    assert_bits_equal(d["pos"], o.positions(), f"seed {seed} positions")
+    assert_bits_equal(d["vel"], o.velocities(), f"seed {seed} velocities")
+    ss = ctx.download_solver_state()
+    assert_bits_equal(ss["kappa"], o.kappa(), "kappa")
+    assert_bits_equal(ss["stiffness"], o.stiffness(), "stiffness")
