@@ -25,9 +25,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False):
     """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the 16-bit list format
-    of this build — every list-consuming traversal moves 2*kbar + 12 (entries, count word, base pair) instead of 4*kbar + 8."""
+    of this build — every list-consuming traversal moves 2*kbar + 4.125 (entries, count word, the wave's base pair / 64) instead of
+    4*kbar + 8."""
     if compressed:
-        return 252 + 16 + 8 * kbar + Id * (84 + 8 + 4 * kbar) + Iv * (80 + 8 + 4 * kbar) + (Wd + Wv) * (44 + 4 + 2 * kbar)
+        return 236.5 + 8 * kbar + Id * (76.25 + 4 * kbar) + Iv * (72.25 + 4 * kbar) + (Wd + Wv) * (40.125 + 2 * kbar)
     return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar)
 
 

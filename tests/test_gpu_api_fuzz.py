@@ -31,12 +31,15 @@ def test_api_sequence(seed):
     timer = y.TimeManager()
     steps_done = 0
 
+    fresh_upload = [False]  # densities are outputs: after an upload they are undefined until the next step has run
+
     def check(what):
         d = ctx.download()
         np.testing.assert_array_equal(d["ids"], o.ids())
         assert_bits_equal(d["pos"], o.positions(), what + ": positions")
         assert_bits_equal(d["vel"], o.velocities(), what + ": velocities")
-        assert_bits_equal(d["density"], o.densities(), what + ": densities")
+        if not fresh_upload[0]:
+            assert_bits_equal(d["density"], o.densities(), what + ": densities")
         ss = ctx.download_solver_state()
         ok, os_ = o.kappa(), o.stiffness()
         if len(ok) == 0:  # right after clear_cached_data the reference's vectors are empty (dfsph.rs:406-412); the device holds zeros
@@ -60,6 +63,7 @@ def test_api_sequence(seed):
                 assert dt_ns == o.timer_step_ns(), (seed, op_i, steps_done)
                 assert st["density_iterations"] == so["density_iterations"] and st["divergence_iterations"] == so["divergence_iterations"]
                 steps_done += 1
+                fresh_upload[0] = False
             check(f"op {op_i} steps")
         elif op in ("grow", "shrink"):
             d = check(f"op {op_i} before {op}")
@@ -72,6 +76,7 @@ def test_api_sequence(seed):
                 p2, v2 = d["pos"][keep], d["vel"][keep]
             ctx.upload(p2, v2)
             o.set_particles(p2, v2)
+            fresh_upload[0] = True
         elif op == "boundary":
             if rng.integers(0, 2):
                 xs = np.arange(0.0, 2.0, 0.01, dtype=np.float32)

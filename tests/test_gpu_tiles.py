@@ -173,3 +173,23 @@ def test_gpu_tile_that_owns_nothing():
             assert a[k] == b[k]
     assert_bits_equal(g[0][0]["pos"], o[0][0]["pos"], "positions")
     assert_bits_equal(g[0][0]["vel"], o[0][0]["vel"], "velocities")
+
+
+@pytest.mark.gpu
+def test_gpu_empty_tile_receives_its_first_particles():
+    """The dam break spreads into a tile that started with nothing: the first records it receives must get cells (its directory is
+    empty until then) and stay — owned counts and every particle agree with the oracle tiles bit for bit."""
+    from tile_oracle_backend import OracleTileBackend
+    from yasph2d_amd.tiles import cell_coord
+
+    pos, boundary = dam_break(1.0)
+    c = cell_coord(pos, 0)
+    cuts = [0, int(c.max()) + 3, 65536]  # the front crosses the cut after a few dozen steps
+    g, _ = run_tiles_threaded(gpu_backend, pos, boundary, 2, 0, 400, halo=8, cuts=cuts)
+    o, _ = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, 2, 0, 400, halo=8, cuts=cuts)
+    assert len(o[1][0]["ids"]) > 0, "scene does not reach the empty tile: lengthen the run"
+    for r in range(2):
+        assert np.array_equal(g[r][0]["ids"], o[r][0]["ids"])
+        assert_bits_equal(g[r][0]["pos"], o[r][0]["pos"], "positions")
+        assert_bits_equal(g[r][0]["vel"], o[r][0]["vel"], "velocities")
+    assert len(g[0][0]["ids"]) + len(g[1][0]["ids"]) == len(pos)

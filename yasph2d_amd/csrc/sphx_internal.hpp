@@ -57,7 +57,7 @@ struct Consts {
 };
 
 // wave-sliced ELL neighbour lists: entry k of particle i; counts[i] = format<<31 | count_total<<16 | count_dynamic;
-// bases[i] = {first dynamic candidate slot, soff + first static candidate slot} (16-bit format only)
+// bases[i >> 6] = {smallest dynamic entry, soff + smallest static entry} of the 64-particle slice (16-bit format only)
 struct NbView {
     const uint32_t* list;
     const uint32_t* counts;

@@ -832,20 +832,30 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         }
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
-        // List format of the staged rows (NbHead): entries ascend, so the first and the last staged entry of each part bound
-        // every 16-bit offset.  Own column of the tile, written by this lane: no barrier needed.
-        uint32_t far = 0;
+        // List format of the staged rows (NbHead): entries ascend, so the first and the last staged entry of each part bound every
+        // lane's range.  Own column of the tile, written by this lane: no barrier needed.
+        uint32_t first_d = 0xFFFFFFFFu, last_d = 0, first_s = 0xFFFFFFFFu, last_s = 0;
         if (cd) {
-            lo_d = mytile[0];
-            far = mytile[(min(cd, STAGE_ROWS) - 1u) * 64] - lo_d;
+            first_d = mytile[0];
+            last_d = mytile[(min(cd, STAGE_ROWS) - 1u) * 64];
         }
         if (ct > cd && cd < STAGE_ROWS) {
-            lo_s = mytile[cd * 64];
-            far |= mytile[(min(ct, STAGE_ROWS) - 1u) * 64] - lo_s;
+            first_s = mytile[cd * 64];
+            last_s = mytile[(min(ct, STAGE_ROWS) - 1u) * 64];
         }
+        // ONE base pair per wave (the smallest dynamic / static entry of its 64 particles), kept per 64-particle slice: a scalar
+        // load for the readers instead of 8 bytes per particle and traversal
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            first_d = min(first_d, (uint32_t)__shfl_xor((int)first_d, d, 64));
+            first_s = min(first_s, (uint32_t)__shfl_xor((int)first_s, d, 64));
+        }
+        lo_d = first_d == 0xFFFFFFFFu ? 0u : first_d;
+        lo_s = first_s == 0xFFFFFFFFu ? 0u : first_s;
+        const uint32_t far = (cd ? last_d - lo_d : 0u) | ((ct > cd && cd < STAGE_ROWS) ? last_s - lo_s : 0u);
         wide = __any(far >= K.span_limit) ? 1u : 0u;
         counts[i] = (wide << 31) | (ct << 16) | cd;
-        bases[i] = make_uint2(lo_d, soff + lo_s);
+        if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) bases[i >> 6] = make_uint2(lo_d, soff + lo_s);
         if (flags) atomicOr(&scal->flags, flags);
     }
     // staged rows -> global, one coalesced row per store (lanes past their own count write don't-care values)
@@ -917,7 +927,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
 // Compressed lists (neighborhood_search.rs:262-273 sketches the idea; README.md:12 calls it WIP).  The entries of one particle
 // are ascending sorted-array indices out of its 3x3 cell box, so they sit within a short span above the first candidate: a
 // wave whose 64 particles all span < 65536 slots stores rows 0..STAGE_ROWS-1 (the rows staged in LDS by the build) as 16-bit
-// offsets from a per-particle base (128-byte rows instead of 256), any other wave keeps 32-bit rows; rows >= STAGE_ROWS are
+// offsets from a per-wave base pair (128-byte rows instead of 256), any other wave keeps 32-bit rows; rows >= STAGE_ROWS are
 // always 32-bit (they lie behind the 16-bit rows of the slice).  The format bit is wave-uniform (bit 31 of every lane's count word).
 struct NbHead {
     uint32_t cd, ct, base_d, base_s, soff;
@@ -934,7 +944,7 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     h.lane = i & 63u;
     h.soff = soff;
-    const uint2 b = nb.bases[i];  // unconditional: issued together with the count word, not after it
+    const uint2 b = nb.bases[__builtin_amdgcn_readfirstlane(i >> 6)];  // one pair per 64-particle slice: a scalar load
     h.base_d = h.wide ? 0u : b.x;
     h.base_s = h.wide ? soff : b.y;
     return h;
