@@ -29,6 +29,8 @@ constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2:
 
 // internal device flag bits (DevScalars::flags)
 constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered block on the fringe of the fluid (offsets stay < 2^31)
+constexpr uint32_t DIR_STATIC = 1u;  // dynamic directory only: the boundary's directory covers this block too (offsets are multiples of 4096)
+constexpr uint32_t DIR_FLAGS = DIR_FRINGE | DIR_STATIC;
 enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
@@ -118,7 +120,8 @@ struct Grid {
     uint32_t* hist = nullptr;  // all-zero between builds; receives the next build's per-cell histogram
     uint32_t fine_cap = 0;     // entries allocated in fine and hist
     uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
-    std::vector<uint8_t> cover;  // dynamic grid, host side: 0 uncovered / 1 interior / 2 fringe per block of the rectangle
+    std::vector<uint8_t> cover;  // dynamic grid, host side: 0 uncovered / 1 interior / 2 fringe per block of the rectangle (static grid: 0 / 1)
+    std::vector<uint32_t> h_dir;  // host copy of dir
     uint32_t len() const { return nblk * BLOCK_CELLS; }
     GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
 };

@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t dir_entry(const GridView& g, uint32_t x, uin
 // index of cell (x,y) (Morton code `code`) in the fine table, or EMPTY if its 64x64 block is not in the directory
 __device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uint32_t y, uint32_t code) {
     const uint32_t off = dir_entry(g, x, y);
-    return off == EMPTY ? EMPTY : (off & ~DIR_FRINGE) + (code & (BLOCK_CELLS - 1u));
+    return off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
 }
 
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV
         uint32_t f = 0;
         const uint32_t code = morton2(cx, cy);
         const uint32_t entry = dropped ? EMPTY : dir_entry(g, cx, cy);
-        idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FRINGE) + (code & (BLOCK_CELLS - 1u));
+        idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
         if (!dropped) {
             if (entry == EMPTY) {
                 if (ring) {
@@ -710,7 +710,9 @@ __device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2
     v = (v | (v << 1)) & 0x555u;
     return v;
 }
-__device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9]) {
+// maybe_static (dynamic grid only): true when one of the nine blocks carries DIR_STATIC or is not covered at all (then nothing is
+// known about it) — only such particles can have static neighbours.
+__device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9], bool* maybe_static = nullptr) {
     // Cells on the rim of the u16 domain: the reference computes the box corners as u16 `pos.x - 1` / `pos.x + 1`
     // (neighborhood_search.rs:193-194), which wrap in a release build (a debug build panics): the x- or y-range of the box is then
     // empty and the particle gets NO neighbours, dynamic or static.  grid_min = -100 keeps real scenes 5000 cells away from the
@@ -726,6 +728,7 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
         by[d] = (y >> BLOCK_SHIFT) - g.by0;
     }
     bool any = false;
+    uint32_t hint = 0;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -733,8 +736,10 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
             uint32_t off = EMPTY;
             if (!rim && bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
             any |= off != EMPTY;
-            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : (off & ~DIR_FRINGE) + (ly[dy] | lx[dx]);
+            hint |= off;  // EMPTY has every bit set
+            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (ly[dy] | lx[dx]);
         }
+    if (maybe_static) *maybe_static = (hint & DIR_STATIC) != 0;
     sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
     return any;
 }
@@ -783,7 +788,8 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         uint32_t* const mytile = &tile[w][0][lane];
         // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
         uint32_t slot[9], s[9], e[9];
-        slots9(gd, cx, cy, slot);
+        bool maybe_static;
+        slots9(gd, cx, cy, slot, &maybe_static);
         ranges9(gd, slot, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -809,8 +815,8 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         }
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
-        const bool near_static = slots9(gs, cx, cy, slot);
-        if (__any(near_static)) {
+        // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
+        if (__any(maybe_static) && __any(slots9(gs, cx, cy, slot))) {
         ranges9(gs, slot, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
