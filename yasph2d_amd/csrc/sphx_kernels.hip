@@ -64,6 +64,18 @@ __device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uin
     return off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
 }
 
+// Correctly rounded sqrt of a squared neighbour distance.  Every list entry passed `d2 > 1e-10` when the list was built and the
+// positions have not moved since, so the argument is a normal number far above 2^-96: the compiler's sqrtf expansion (16
+// instructions) spends 7 of them on rescaling tiny arguments and passing 0/inf/nan through.  What is left is its own correction
+// of v_sqrt_f32 (1 ulp): try one ulp down and one ulp up with exact fma residuals.  (0, inf and nan still come out as sqrtf
+// gives them: every compare below is false for them.)
+__device__ __forceinline__ float sqrt_dist(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+    s = vp <= 0.0f ? sd : s;
+    return vs > 0.0f ? su : s;
+}
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
 __device__ __forceinline__ float wendland_eval(const Consts& K, float r) {
     const float q = fminf(K.w_hinv * r, 1.0f);
@@ -75,7 +87,7 @@ __device__ __forceinline__ float wendland_eval(const Consts& K, float r) {
 __device__ __forceinline__ float2 wendland_grad(const Consts& K, float2 ri, float2 rj) {
     const float dx = rj.x - ri.x, dy = rj.y - ri.y;
     const float r_sq = dx * dx + dy * dy;
-    const float r = sqrtf(r_sq);
+    const float r = sqrt_dist(r_sq);
     const float q = fminf(r * K.w_hinv, 1.0f);
     const float omq = 1.0f - q;
     const float s = K.w_ngrad * omq * omq * omq;
@@ -788,6 +800,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         uint32_t* const mytile = &tile[w][0][lane];
         // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
         uint32_t slot[9], s[9], e[9];
+        const uint32_t wlen_b = wlen * 8u;
         bool maybe_static;
         slots9(gd, cx, cy, slot, &maybe_static);
         ranges9(gd, slot, s, e);
@@ -796,23 +809,41 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
             // software pipeline: the next candidate's ds_read is in flight while the current one is tested.  The out-of-window
             // re-read stays INSIDE the loop: per (lane, cell) it is rare, but some lane of a wave needs it for most cells, and a
             // separate slow loop would then run after the fast one for nearly every wave (measured: +5 us).
-            float2 pn = lds_read_f2(&win[min(s[t] - w0, wlen)]);
-            for (uint32_t j = s[t]; j < e[t]; ++j) {
-                const uint32_t wj = j - w0;
-                float2 pj = pn;
-                pn = lds_read_f2(&win[min(wj + 1u, wlen)]);  // win[wlen] is the pad slot
-                if (wj >= wlen) pj = gat(posA, j);
-                const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-                const float d2 = dx * dx + dy * dy;
-                if (d2 <= K.radius_sq && d2 > 1.0e-10f && ct < MAX_NEIGHBORS) {
-                    if (ct < STAGE_ROWS)
-                        mytile[ct * 64] = j;
-                    else
-                        list[ell_index(i, ct)] = j;
-                    ct += 1;
+            // The kernel is VALU-bound and this loop is half of its instructions, so it is written for instruction count:
+            // * it runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), negative for j < w0; n < 2^28): the j is
+            //   only formed for accepted candidates;
+            // * two candidates per trip with the two position registers swapping roles, so the pipelined value is never copied;
+            // * the 64-entry cap is not tested here: entries past it are stored to a don't-care word and ct is clamped afterwards.
+            const uint32_t eb = (e[t] - w0) * 8u;
+            uint32_t ab = (s[t] - w0) * 8u;
+            if (ab != eb) {
+                float2 p0 = lds_read_f2((const float2*)((const char*)win + min(ab, wlen_b))), p1;
+                auto test = [&](float2 pj) {
+                    if (ab >= wlen_b) pj = gat(posA, w0 + (uint32_t)((int32_t)ab >> 3));
+                    const float dx = pj.x - pi.x, dy = pj.y - pi.y;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
+                        const uint32_t j = w0 + (uint32_t)((int32_t)ab >> 3);
+                        if (ct < STAGE_ROWS)
+                            mytile[ct * 64] = j;
+                        else
+                            *(ct < MAX_NEIGHBORS ? &list[ell_index(i, ct)] : &counts[i]) = j;  // counts[i] is written below
+                        ct += 1;
+                    }
+                };
+                for (;;) {
+                    p1 = lds_read_f2((const float2*)((const char*)win + min(ab + 8u, wlen_b)));  // win[wlen] is the pad slot; -8 + 8 = 0: a range may enter the window
+                    test(p0);
+                    ab += 8u;
+                    if (ab == eb) break;
+                    p0 = lds_read_f2((const float2*)((const char*)win + min(ab + 8u, wlen_b)));
+                    test(p1);
+                    ab += 8u;
+                    if (ab == eb) break;
                 }
             }
         }
+        ct = min(ct, MAX_NEIGHBORS);
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
         // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
@@ -892,7 +923,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
                 rj = gat(posA, soff + j);
             }
             const float dx = rj.x - pi.x, dy = rj.y - pi.y;
-            const float r = sqrtf(dx * dx + dy * dy);
+            const float r = sqrt_dist(dx * dx + dy * dy);
             const float q = fminf(r * K.w_hinv, 1.0f);
             const float omq = 1.0f - q;
             const float omq_sq = omq * omq;
@@ -1019,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
             const bool live = k < ct;
             const float dx = rj.x - ri.x, dy = rj.y - ri.y;
             const float r_sq = dx * dx + dy * dy;
-            const float r = sqrtf(r_sq);
+            const float r = sqrt_dist(r_sq);
             if (DENSITY) {
                 float wv;
                 if (KIND == 0) wv = wendland_eval(K, r);
@@ -1212,7 +1243,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
             [&](const Rec& q, uint32_t k) {
                 const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
                 const float r_sq = dx * dx + dy * dy;
-                const float r = sqrtf(r_sq);
+                const float r = sqrt_dist(r_sq);
                 float tx, ty;
                 if (k < cd) {
                     const float pj = wcsph_pressure(K, q.rho);
