@@ -730,23 +730,37 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
     // empty and the particle gets NO neighbours, dynamic or static.  grid_min = -100 keeps real scenes 5000 cells away from the
     // rim; the rule is restated for parity (tests/test_gpu_random_scenes.py puts a sheet of fluid into the corner).
     const bool rim = cx - 1u >= 65534u || cy - 1u >= 65534u;
-    uint32_t lx[3], ly[3], bx[3], by[3];
+    // Low 6 bits of x-1, x, x+1 spread to the even bit positions (y: odd).  Spread once; the neighbours follow by dilated
+    // decrement / increment, which wrap 0 <-> 63 like the cell coordinate does at a block edge.
+    uint32_t lx[3], ly[3], bx[3], row[3];
+    bool vx[3], vy[3];
+    lx[1] = spread6(cx);
+    lx[0] = (lx[1] - 1u) & 0x555u;
+    lx[2] = ((lx[1] | ~0x555u) + 1u) & 0x555u;
+    const uint32_t sy = spread6(cy);
+    ly[1] = sy << 1;
+    ly[0] = ((sy - 1u) & 0x555u) << 1;
+    ly[2] = (((sy | ~0x555u) + 1u) & 0x555u) << 1;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
-        lx[d] = spread6(x);
-        ly[d] = spread6(y) << 1;
         bx[d] = (x >> BLOCK_SHIFT) - g.bx0;
-        by[d] = (y >> BLOCK_SHIFT) - g.by0;
+        const uint32_t by = (y >> BLOCK_SHIFT) - g.by0;
+        vx[d] = !rim && bx[d] < g.nbx;
+        vy[d] = by < g.nby;
+        row[d] = __umul24(by, g.nbx);  // both < 2^10 when the entry is used
     }
     bool any = false;
     uint32_t hint = 0;
+    // every load unconditional (entry 0 for boxes that leave the directory; the directory always has one readable entry): nine
+    // loads in flight together instead of nine branches
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            uint32_t off = EMPTY;
-            if (!rim && bx[dx] < g.nbx && by[dy] < g.nby) off = gat(g.dir, by[dy] * g.nbx + bx[dx]);
+            const bool ok = vx[dx] && vy[dy];
+            uint32_t off = gat(g.dir, ok ? row[dy] + bx[dx] : 0u);
+            off = ok ? off : EMPTY;
             any |= off != EMPTY;
             hint |= off;  // EMPTY has every bit set
             slot[dy * 3 + dx] = off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (ly[dy] | lx[dx]);
@@ -758,10 +772,10 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
 __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        uint2 se = make_uint2(0u, 0u);
-        if (slot[t] != EMPTY) se = gat(g.fine, slot[t]);
-        s[t] = se.x;
-        e[t] = se.y;
+        const bool ok = slot[t] != EMPTY;
+        const uint2 se = gat(g.fine, ok ? slot[t] : 0u);  // unconditional: the table always has one readable entry
+        s[t] = ok ? se.x : 0u;
+        e[t] = ok ? se.y : 0u;
     }
 }
 
@@ -820,8 +834,11 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
                 float2 p0 = lds_read_f2((const float2*)((const char*)win + min(ab, wlen_b))), p1;
                 auto test = [&](float2 pj) {
                     if (ab >= wlen_b) pj = gat(posA, w0 + (uint32_t)((int32_t)ab >> 3));
-                    const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-                    const float d2 = dx * dx + dy * dy;
+                    // both components in one packed instruction each (v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations, no fusion)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 d = f32x2{pj.x, pj.y} - f32x2{pi.x, pi.y};
+                    const f32x2 q = d * d;
+                    const float d2 = q.x + q.y;
                     if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
                         const uint32_t j = w0 + (uint32_t)((int32_t)ab >> 3);
                         if (ct < STAGE_ROWS)
