@@ -205,6 +205,20 @@ def test_list_formats_do_not_change_results(span):
     run_steps(ctx, o, 330, check_every=55)
 
 
+def test_two_pass_scan_switch(monkeypatch):
+    """SPHX_SCAN_TWO_PASS=1 selects the two-launch cell-table scan (kept for A/B timing); the default is the one-launch
+    look-back scan.  Both must give the oracle's grid and states — at 40 k particles the table spans several scan tiles, so the
+    look-back really crosses workgroups."""
+    s = float(np.sqrt(40000 / 4050))
+    pos, boundary = dam_break(s)
+    monkeypatch.setenv("SPHX_SCAN_TWO_PASS", "1")
+    ctx, o = make_pair(pos, boundary)
+    ctx.update_neighborhood()
+    o.update_neighborhood()
+    compare_grid(ctx, o)
+    run_steps(ctx, o, 12, check_every=6)
+
+
 def test_dfsph_scale_40k():
     s = float(np.sqrt(40000 / 4050))
     pos, boundary = dam_break(s)

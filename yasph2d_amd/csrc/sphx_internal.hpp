@@ -31,7 +31,7 @@ constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2:
 constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered block on the fringe of the fluid (offsets stay < 2^31)
 constexpr uint32_t DIR_STATIC = 1u;  // dynamic directory only: the boundary's directory covers this block too (offsets are multiples of 4096)
 constexpr uint32_t DIR_FLAGS = DIR_FRINGE | DIR_STATIC;
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u };
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
 constexpr uint32_t MAX_TILE_PEERS = 8;  // a rectangle has at most 8 neighbours (4 edges + 4 corners) in a regular tiling
@@ -201,6 +201,9 @@ struct sphx_ctx {
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;
+    unsigned long long* scan_state = nullptr;  // one-pass scan: {epoch, flag, value} per 4096-entry tile
+    uint32_t scan_state_cap = 0, scan_epoch = 0;
+    int scan_two_pass = 0;  // SPHX_SCAN_TWO_PASS=1: the two-launch scan (A/B runs)
     double* red_partials = nullptr;  // one slot per workgroup (also reinterpreted as u32 for the max reduction)
     // scalars
     sphx::DevScalars* d_scal = nullptr;

@@ -332,6 +332,107 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t* __restrict__ in, u
     }
 }
 
+// The same scan in ONE launch (decoupled look-back): every workgroup publishes the sum of its tile, then adds up the published
+// words of its predecessors until it meets one that already knows its inclusive prefix.  A word carries {epoch, flag, value}
+// in 64 bits, so one agent-scope load sees a consistent pair and nothing has to be reset between builds (the epoch changes).
+// A workgroup only ever waits for LOWER workgroup ids, which were dispatched before it: no deadlock.  The wait is bounded all the
+// same: a stall raises DF_SCAN_STALL (the host fails the call) instead of hanging the device.
+constexpr uint32_t SCAN_AGG = 1u, SCAN_PREFIX = 2u;
+__device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t flag, uint32_t value) {
+    return ((unsigned long long)epoch << 32) | ((unsigned long long)flag << 30) | value;  // value < 2^30 (contexts hold < 2^28 slots)
+}
+__global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in, uint2* __restrict__ out, uint32_t len,
+                                                       unsigned long long* __restrict__ state, uint32_t epoch,
+                                                       DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total) {
+    const uint32_t bid = blockIdx.x;
+    const uint32_t base = bid * SCAN_TILE;
+    uint32_t v[16];
+    uint32_t s = 0;
+    const uint32_t t0 = base + threadIdx.x * 16;
+    const bool full = t0 + 16 <= len;
+    if (full) {
+        uint4* p4 = reinterpret_cast<uint4*>(in + t0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 q = p4[k];
+            v[4 * k] = q.x;
+            v[4 * k + 1] = q.y;
+            v[4 * k + 2] = q.z;
+            v[4 * k + 3] = q.w;
+            p4[k] = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = (t0 + k < len) ? in[t0 + k] : 0;
+            if (t0 + k < len) in[t0 + k] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(s, &total);
+    __shared__ uint32_t excl_s;
+    if (threadIdx.x == 0) {
+        excl_s = 0;
+        __hip_atomic_store(&state[bid], scan_word(epoch, bid == 0 ? SCAN_PREFIX : SCAN_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (bid > 0 && threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t excl = 0;
+        int32_t j = (int32_t)bid - 1 - (int32_t)lane;  // lane 0 looks at the nearest predecessor
+        for (;;) {
+            unsigned long long st = 0;
+            uint32_t spins = 0;
+            bool ready;
+            do {
+                st = j >= 0 ? __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : scan_word(epoch, SCAN_PREFIX, 0u);
+                ready = (uint32_t)(st >> 32) == epoch && ((st >> 30) & 3u) != 0u;
+            } while (!__all(ready) && ++spins < (1u << 22));
+            if (!__all(ready)) {
+                if (lane == 0) atomicOr(&scal->flags, DF_SCAN_STALL);
+                break;
+            }
+            const uint32_t val = (uint32_t)st & 0x3FFFFFFFu;
+            const unsigned long long known = __ballot(((st >> 30) & 3u) == SCAN_PREFIX);
+            const uint32_t first = known ? (uint32_t)__ffsll((long long)known) - 1u : 63u;
+            uint32_t part = lane <= first ? val : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            excl += part;
+            if (known) break;
+            j -= 64;
+        }
+        if (lane == 0) {
+            excl_s = excl;
+            __hip_atomic_store(&state[bid], scan_word(epoch, SCAN_PREFIX, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    run += excl_s;
+    if (bid == gridDim.x - 1 && threadIdx.x == 0 && d_total) *d_total = excl_s + total;  // grand total = particles that got a cell
+    if (full) {
+        uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 q;
+            q.x = run;
+            run += v[2 * k];
+            q.y = run;
+            q.z = run;
+            run += v[2 * k + 1];
+            q.w = run;
+            o4[k] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (t0 + k < len) out[t0 + k] = make_uint2(run, run + v[k]);
+            run += v[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // grid build: a1 (cell index), a2 (counting sort by Morton key, stable), a3 (gather), a4 (cells = fine table)
 // ------------------------------------------------------------------------------------------------------------------
