@@ -91,12 +91,14 @@ def run_steps(ctx, o, steps, check_every=1, use_law=True):
     unless the host timer arrives at the same bits, so every step also checks the device restatement of the timer law."""
     timer = y.TimeManager()
     diam = np.float32(2.0) * np.float32(0.005)
+    all_stats = []
     for s in range(steps):
         dt_prev = timer.simulation_step()
         vmax = ctx.step_begin(dt_prev, timer.law(diam) if use_law else None)
         dt_ns = timer.update_simulation_step(diam, vmax)
         st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
         so = o.dfsph_step()
+        all_stats.append(st)
         assert o.timer_step_ns() == dt_ns, f"step {s}: dt differs"
         assert np.float32(vmax) == np.float32(so["vmax"]), f"step {s}: vmax {vmax} vs {so['vmax']}"
         for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence", "neighbor_entries"):
@@ -115,6 +117,7 @@ def run_steps(ctx, o, steps, check_every=1, use_law=True):
             assert_bits_equal(ss["kappa"], o.kappa(), f"step {s} kappa")
             assert_bits_equal(ss["stiffness"], o.stiffness(), f"step {s} stiffness")
     assert_same_neighbors(ctx.download_neighbors(), o.neighbors())
+    return all_stats
 
 
 def test_dfsph_dam_break_adaptive_400_steps():
@@ -217,6 +220,27 @@ def test_two_pass_scan_switch(monkeypatch):
     o.update_neighborhood()
     compare_grid(ctx, o)
     run_steps(ctx, o, 12, check_every=6)
+
+
+def test_fused_count_switch(monkeypatch):
+    """The last density correction of a step also does the advection + cell count of the re-grid that follows (CountArgs);
+    SPHX_NO_FUSED_COUNT=1 keeps the separate count pass.  Both must follow the oracle bit for bit — with the adaptive loop, and
+    with 3 fixed density iterations per step, where every correction counts and the first two counts of each step are thrown
+    away (the histogram is cleared again)."""
+    pos, boundary = dam_break(1.0)
+    for fixed, steps in (((0, 0), 120), ((3, 2), 60)):  # (the fixed-iteration scene blows up after ~100 steps)
+        monkeypatch.setenv("SPHX_NO_FUSED_COUNT", "1")
+        ctx, o = make_pair(pos, boundary, fixed=fixed)
+        stats = run_steps(ctx, o, steps, check_every=20, use_law=fixed == (0, 0))
+        monkeypatch.delenv("SPHX_NO_FUSED_COUNT")
+        ctx2, o2 = make_pair(pos, boundary, fixed=fixed)
+        stats2 = run_steps(ctx2, o2, steps, check_every=20, use_law=fixed == (0, 0))
+        assert [s["density_iterations"] for s in stats] == [s["density_iterations"] for s in stats2]
+        if fixed[0]:
+            assert stats2[-1]["density_iterations"] == fixed[0]
+        a, b = ctx.download(), ctx2.download()
+        for k in ("pos", "vel", "density"):
+            assert_bits_equal(a[k], b[k], k)
 
 
 def test_dfsph_scale_40k():

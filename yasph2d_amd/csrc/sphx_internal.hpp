@@ -203,6 +203,10 @@ struct sphx_ctx {
     uint32_t scan_partials_cap = 0;
     unsigned long long* scan_state = nullptr;  // one-pass scan: {epoch, flag, value} per 4096-entry tile
     uint32_t scan_state_cap = 0, scan_epoch = 0;
+    bool fuse_count_ok = false;  // inside sphx_step_finish / _begin_law: the density correction may do the re-grid's cell count
+    bool count_done = false;     // gdyn.hist / key / slot hold the count of the latest density correction (not yet consumed)
+    uint32_t count_n = 0;
+    int no_fused_count = 0;      // SPHX_NO_FUSED_COUNT=1 (A/B runs)
     int scan_two_pass = 0;  // SPHX_SCAN_TWO_PASS=1: the two-launch scan (A/B runs)
     double* red_partials = nullptr;  // one slot per workgroup (also reinterpreted as u32 for the max reduction)
     // scalars

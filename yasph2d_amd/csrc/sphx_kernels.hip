@@ -441,24 +441,12 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
 // ago), so equal cells sit in adjacent lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.
 // The value returned by the atomic is an arbitrary arrival slot inside the cell; k_rank_gather restores the stable order.
 // cidx[i] = the particle's index into the fine table (kept for scatter/gather).
-template <bool ADVECT>
-__global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV, const float2* __restrict__ pos_in,
-                                                    uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
-                                                    uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
-                                                    DevScalars* __restrict__ scal) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+// Called by ALL lanes of a wavefront (live = this lane holds particle i at position p).
+__device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, bool live, uint32_t i, float2 p, uint32_t* __restrict__ hist,
+                                           uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring, DevScalars* __restrict__ scal) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = EMPTY;
-    if (i < n) {
-        float2 p;
-        if (ADVECT) {
-            // the advected position is only needed for the key here; k_rank_gather repeats the same two operations when it moves
-            // the record, so this pass writes neither PV nor posA (24 B per particle less)
-            const float4 pv = PV[i];
-            p = make_float2(pv.x + pv.z * dt, pv.y + pv.w * dt);
-        } else {
-            p = pos_in[i];
-        }
+    if (live) {
         uint32_t cx, cy;
         cell_of(K, p, cx, cy);
         const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
@@ -493,7 +481,26 @@ __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV
     uint32_t base = 0;
     if (head && idx != EMPTY) base = atomicAdd(&hist[idx], end - lane);
     base = __shfl(base, start, 64);
-    if (i < n) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
+    if (live) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
+}
+template <bool ADVECT>
+__global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV, const float2* __restrict__ pos_in,
+                                                    uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
+                                                    uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
+                                                    DevScalars* __restrict__ scal) {
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    float2 p = make_float2(0.0f, 0.0f);
+    if (i < n) {
+        if (ADVECT) {
+            // the advected position is only needed for the key here; k_rank_gather repeats the same two operations when it moves
+            // the record, so this pass writes neither PV nor posA (24 B per particle less)
+            const float4 pv = PV[i];
+            p = make_float2(pv.x + pv.z * dt, pv.y + pv.w * dt);
+        } else {
+            p = pos_in[i];
+        }
+    }
+    count_cell(K, g, i < n, i, p, hist, cidx, slot, ring, scal);
 }
 
 // order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order)
@@ -1451,57 +1458,75 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // a16 / a21: correct_{density,divergence}_error_warmstart (dfsph.rs:163-193 / 316-344) incl. the clamp of :201-203 / :356-358
 // ------------------------------------------------------------------------------------------------------------------
 // WARM=false: k comes from PK (own and neighbours'), warm[i] += k_i.   WARM=true: k = 0.5*max(warm, lim) (clamp applied on read).
+// The LAST density correction of a step leaves the final predicted velocity of its particle in registers: that is all the
+// advection + cell count of the re-grid that follows (k_key_count<true>) needs, so the correction does it on the spot and the
+// re-grid starts at the scan.  Whether a correction is the last one is only known afterwards (the residual decides): every density
+// correction counts, and the host clears the histogram again when another iteration follows.  hist == nullptr: plain correction.
+struct CountArgs {
+    GridView g;
+    uint32_t *hist, *cidx, *slot;
+    float dt;  // the step (host value; with dt_dev the device's)
+};
 template <bool WARM, bool INV_DT>
 __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
-                                                  const float* __restrict__ dt_dev) {
-    if (dt_dev) inv_dt = 1.0f / *dt_dev;
+                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal) {
+    float dt = ca.dt;
+    if (dt_dev) {
+        dt = *dt_dev;
+        inv_dt = 1.0f / dt;
+    }
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
-    if (i >= n) return;
-    const NbHead h = nb_head(nb, i, soff);
-    const uint32_t cd = h.cd, ct = h.ct;
-    const float4 pvi = PV[i];
-    float ki;
-    float2 ri;
-    if (WARM) {
-        ki = 0.5f * fmaxf(warm[i], lim);
-        ri = make_float2(pvi.x, pvi.y);
-    } else {
-        const float4 pki = PK[i];
-        ki = pki.z;
-        ri = make_float2(pki.x, pki.y);
+    float2 pnew = make_float2(0.0f, 0.0f);
+    if (i < n) {
+        const NbHead h = nb_head(nb, i, soff);
+        const uint32_t cd = h.cd, ct = h.ct;
+        const float4 pvi = PV[i];
+        float ki;
+        float2 ri;
+        if (WARM) {
+            ki = 0.5f * fmaxf(warm[i], lim);
+            ri = make_float2(pvi.x, pvi.y);
+        } else {
+            const float4 pki = PK[i];
+            ki = pki.z;
+            ri = make_float2(pki.x, pki.y);
+        }
+        float dx = 0.0f, dy = 0.0f;
+        struct Rec {
+            float4 r;
+            float w;
+        };
+        nb_traverse(
+            h, ct,
+            [&](uint32_t slot) {
+                // warm[] has no boundary tail; static entries do not use it
+                if (WARM) return Rec{gat((const float4*)PV, slot), gat((const float*)warm, slot < soff ? slot : i)};
+                return Rec{gat(PK, slot), 0.0f};
+            },
+            [&](const Rec& q, uint32_t k) {
+                const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
+                // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
+                const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
+                const float s = k < cd ? ki + kj : ki;
+                const float tx = dx + s * g.x, ty = dy + s * g.y;
+                dx = k < ct ? tx : dx;
+                dy = k < ct ? ty : dy;
+            });
+        float2 o;
+        if (INV_DT) {
+            o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
+            o.y = pvi.w - (inv_dt * dy) * K.mass;
+        } else {
+            o.x = pvi.z - dx * K.mass;  // dfsph.rs:312 / :342
+            o.y = pvi.w - dy * K.mass;
+        }
+        PV[i] = make_float4(pvi.x, pvi.y, o.x, o.y);
+        if (!WARM) warm[i] += ki;  // dfsph.rs:142 / :296
+        pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
-    float dx = 0.0f, dy = 0.0f;
-    struct Rec {
-        float4 r;
-        float w;
-    };
-    nb_traverse(
-        h, ct,
-        [&](uint32_t slot) {
-            // warm[] has no boundary tail; static entries do not use it
-            if (WARM) return Rec{gat((const float4*)PV, slot), gat((const float*)warm, slot < soff ? slot : i)};
-            return Rec{gat(PK, slot), 0.0f};
-        },
-        [&](const Rec& q, uint32_t k) {
-            const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
-            // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
-            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
-            const float s = k < cd ? ki + kj : ki;
-            const float tx = dx + s * g.x, ty = dy + s * g.y;
-            dx = k < ct ? tx : dx;
-            dy = k < ct ? ty : dy;
-        });
-    float2 o;
-    if (INV_DT) {
-        o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
-        o.y = pvi.w - (inv_dt * dy) * K.mass;
-    } else {
-        o.x = pvi.z - dx * K.mass;  // dfsph.rs:312 / :342
-        o.y = pvi.w - dy * K.mass;
-    }
-    PV[i] = make_float4(pvi.x, pvi.y, o.x, o.y);
-    if (!WARM) warm[i] += ki;  // dfsph.rs:142 / :296
+    if (!WARM && INV_DT)
+        if (ca.hist) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
