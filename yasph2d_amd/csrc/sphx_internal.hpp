@@ -23,8 +23,14 @@ constexpr uint32_t MAX_NEIGHBORS = 64;  // neighborhood_search.rs:322
 constexpr uint32_t BLOCK_SHIFT = 6;     // directory blocks are 64x64 cells
 constexpr uint32_t BLOCK_CELLS = 4096;  // cells per block = low 12 Morton bits
 constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 threads x 16)
-constexpr uint32_t STAGE_ROWS = 16;     // neighbour rows staged in LDS per wave before the coalesced row store
-constexpr uint32_t WIN_HALO = 256;      // neighbour build: positions of [block_first - 256, block_last + 256] are staged in LDS
+#ifndef SPHX_STAGE_ROWS
+#define SPHX_STAGE_ROWS 12
+#endif
+#ifndef SPHX_WIN_HALO
+#define SPHX_WIN_HALO 256
+#endif
+constexpr uint32_t STAGE_ROWS = SPHX_STAGE_ROWS;     // neighbour rows staged in LDS per wave before the coalesced row store
+constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions of [block_first - 256, block_last + 256] are staged in LDS
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
