@@ -888,7 +888,7 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 }
 
 // 8 waves per SIMD = 8 workgroups per CU: 12 staged rows (12 KiB) + the window (6 KiB) keep a workgroup at 18 KiB of the CU's
-// 160 KiB, and the register budget of 64 costs 6 spilled VGPRs.  At 1 M particles the 3 906 workgroups then fit into two "rounds"
+// 160 KiB, and the kernel fits the register budget of 64 without spills.  At 1 M particles the 3 906 workgroups then fit into two "rounds"
 // of the chip instead of 2.2 (16 rows / 7 waves: +3.5 us; 12 rows at 7 waves: no change — it is the occupancy that pays).
 #ifndef NB_BOUNDS
 #define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -974,7 +974,11 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
         // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
-        if (__any(maybe_static) && __any(slots9(gs, cx, cy, slot))) {
+        // (cx, cy pass through an opaque asm so that the compiler recomputes the nine local offsets here instead of keeping them alive
+        // — spilled — across the whole candidate section for a block that most waves never enter)
+        uint32_t cxs = cx, cys = cy;
+        asm volatile("" : "+v"(cxs), "+v"(cys));
+        if (__any(maybe_static) && __any(slots9(gs, cxs, cys, slot))) {
         ranges9(gs, slot, s, e);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
