@@ -2,7 +2,12 @@
 """bench.py — particle-steps/sec of the 2D DFSPH dam-break (BASELINE.json metric) on N MI355X of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 started WITHOUT a launcher (no RANK in the environment) starts the N ranks itself: before anything touches
+the GPU this process runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+<same arguments>` as a CHILD process (never an exec of a GPU-touching process), forwards rank 0's one JSON line and exits with the
+child's status.  Started under a launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`), WORLD_SIZE must
+equal --gpus or the run fails loudly.  One process per GPU; RCCL ("nccl") carries the halo records.
 
 A "step" is one Solver::simulation_step (dfsph.rs:414-525) of the dam-break scene of main.rs:177-196 scaled to ~P
 particles per GPU, driven exactly like the drop-in shim would drive it: sphx_step_begin -> host TimeManager CFL law ->
@@ -60,6 +65,41 @@ def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
     }
 
 
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a CHILD process tree and forward rank 0's line.
+    Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise HIP on this image)."""
+    import socket
+    import subprocess
+
+    if args.backend == "nccl" and not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible (one rank per GPU over RCCL; "
+                             f"--backend gloo lets ranks share a GPU for functional tests)\n")
+            return 2
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / device-buffer sharing across processes needs it on this pool
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode}, {len(lines)} result lines); command: {' '.join(cmd)}\n")
+        return proc.returncode or 1
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} ranks but the result line reports n_gpus = {out.get('n_gpus')}\n")
+        return 1
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +123,20 @@ def main():
     ap.add_argument("--no-device-dt", action="store_true", help="plain sphx_step_begin: the device waits for the host's dt (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test: ranks rendezvous (gloo), barrier, all-reduce and print the line with value = null; no GPU, no compute")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    launched = "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {env_world}: start it as `python bench.py --gpus {args.gpus} ...` (it launches "
+                 f"its own ranks) or as `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                 f"--master-port P bench.py --gpus {args.gpus} ...`")
 
     # Exactly ONE line on stdout: RCCL prints a version banner and gloo its connection notes to fd 1, from C code.  Everything
     # written to fd 1 during the run goes to stderr; the result line is written to the saved descriptor at the end.
@@ -96,6 +149,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seen = torch.tensor([1.0], dtype=torch.float64)
+            dist.all_reduce(seen)  # every rank arrived
+            assert int(seen.item()) == world
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"metric": "particle-steps/sec (whole node), 2D DFSPH dam-break", "value": None,
+                                             "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                             "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                                             "dtype": "f32", "data": "none (dry run of the rank launcher)",
+                                             "config": {"workload": "dry run: no compute"}}) + "\n").encode())
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev
     if world > 1 or (args.force_tiles and "RANK" in os.environ):  # world 1 under torchrun + --force-tiles: exercises the collectives alone
@@ -270,6 +347,7 @@ def main():
             "value": value,
             "unit": "particle-steps/s",
             "n_gpus": world,
+            "world_size_seen": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
