@@ -121,6 +121,10 @@ def main():
     ap.add_argument("--solver", default="dfsph", choices=["dfsph", "wcsph"],
                     help="wcsph: the second Solver of the reference (solver/wscsph.rs, cfl factor 0.2, main.rs:116-119) on one GPU")
     ap.add_argument("--no-device-dt", action="store_true", help="plain sphx_step_begin: the device waits for the host's dt (A/B runs)")
+    ap.add_argument("--fixed-iterations", type=int, nargs=2, default=(0, 0), metavar=("ID", "IV"),
+                    help="run exactly ID constant-density and IV divergence iterations per step (0 0 = adaptive, the reference's behaviour)")
+    ap.add_argument("--tolerance-scale", type=float, default=1.0,
+                    help="multiply both solver tolerances (dfsph.rs:49,53) by this; < 1 makes the loops iterate (the iterating-regime window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -198,7 +202,10 @@ def main():
     n_global = len(pos)
     diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
     timer = y.TimeManager(cfl_factor=0.2) if args.solver == "wcsph" else y.TimeManager()
-    params = y.default_params(device=dev_index)
+    params = y.default_params(device=dev_index, fixed_iterations=tuple(args.fixed_iterations))
+    if args.tolerance_scale != 1.0:
+        params.max_avg_density_error = float(np.float32(params.max_avg_density_error) * np.float32(args.tolerance_scale))
+        params.max_divergence_error = float(np.float32(params.max_divergence_error) * np.float32(args.tolerance_scale))
     if args.lists_32bit:
         params.list_span_limit = y.LISTS_32BIT
     ctx = y.SphxContext(params)
@@ -359,7 +366,9 @@ def main():
             "config": {
                 "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
                             f"in total ({n} fluid per GPU), adaptive CFL timer from t=0"
-                            + (f", window after {args.skip_steps} steps" if args.skip_steps else "") + ", two-phase step through the C ABI",
+                            + (f", window after {args.skip_steps} steps" if args.skip_steps else "")
+                            + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
+                            + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "particles_total": n_global,
                 "parallelism": "single GPU" if tiled is None else
@@ -367,6 +376,10 @@ def main():
                 f"exchange (send/recv with {len(tiled.peers)} neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
                 f"{tiled.rebalances} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
+                "max_density_iterations_seen": int(max(s["density_iterations"] for s in stats)),
+                "max_divergence_iterations_seen": int(max(s["divergence_iterations"] for s in stats)),
+                "solver_loop": "host-run (SPHX_HOST_LOOP=1)" if os.environ.get("SPHX_HOST_LOOP") == "1" else
+                "device-run (residual test on the device, iterations queued ahead)" if tiled is None else "host-run with an all-reduce per iteration",
             },
             "step_model": {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
                            "list_format": "32-bit" if args.lists_32bit else "16-bit offsets (32-bit fallback per wave)",

@@ -240,3 +240,45 @@ def test_far_apart_pools_use_a_sparse_directory():
     for _ in range(30):
         step_both(ctx, o, timer)
     compare_state(ctx, o, "two pools")
+
+
+def test_device_run_solver_loops_equal_host_run_loops(monkeypatch):
+    """The residual test of dfsph.rs:221-236 / :376-391 runs on the device (LoopArgs: iterations queued ahead, the terminating one
+    marks the loop done, the rest return at once); SPHX_HOST_LOOP=1 keeps the host in the loop.  Same bits, same counts — through
+    the impact of the reference scene, where the counts jump up and down (under- and over-predicted queues) and warm starts fire;
+    and with tolerances tight enough that the density loop iterates too."""
+    pos, boundary = dam_break(1.0)
+
+    def run(host_loop, tight):
+        if host_loop:
+            monkeypatch.setenv("SPHX_HOST_LOOP", "1")
+        else:
+            monkeypatch.delenv("SPHX_HOST_LOOP", raising=False)
+        p = y.default_params()
+        if tight:
+            p.max_avg_density_error = np.float32(1e-8)
+            p.max_divergence_error = np.float32(1e-6)
+            p.max_density_iterations = 7   # the cap (+1) is reached: dfsph.rs:236
+        ctx = y.SphxContext(p)
+        ctx.set_boundary(boundary)
+        ctx.upload(pos)
+        timer = y.TimeManager()
+        counts = []
+        for _ in range(120 if tight else 450):
+            vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
+            st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(np.float32(0.01), vmax)))
+            counts.append((st["density_iterations"], st["divergence_iterations"], st["warmstart_density"], st["warmstart_divergence"], st["flags"] & 6,
+                           np.float32(st["avg_density_error"]).tobytes(), np.float32(st["avg_divergence"]).tobytes()))
+        return ctx.download(), ctx.download_solver_state(), counts
+
+    for tight in (False, True):
+        da, sa, ca = run(False, tight)
+        db, sb, cb = run(True, tight)
+        assert ca == cb
+        assert max(c[1] for c in ca) > 3 and sum(c[2] + c[3] for c in ca) > 10
+        if tight:
+            assert max(c[0] for c in ca) == 8 and any(c[4] & 2 for c in ca), "the density loop must have hit its iteration cap"
+        for k in ("pos", "vel", "density"):
+            assert_bits_equal(da[k], db[k], k)
+        for k in ("kappa", "stiffness", "alpha"):
+            assert_bits_equal(sa[k], sb[k], k)

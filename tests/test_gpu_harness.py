@@ -57,3 +57,33 @@ def test_harness_matches_python_driver(solver, extra):
 def test_harness_rejects_unknown_arguments():
     out = subprocess.run([HARNESS, "--bogus"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 2
+
+
+@pytest.mark.gpu
+def test_headless_world_is_not_rewound_by_a_mid_run_edit():
+    """Round-1 advisor finding: with sync_world = 0 the host arrays are stale, and add_fluid_rect mid-run made the next step re-upload
+    them — rewinding the fluid to its last synced state.  The reference's caller always edits a CURRENT world (the solver works on
+    the Vecs in place), so the mirror now fetches the stale prefix before it uploads an edited world: headless stepping and synced
+    stepping must give the same bits."""
+    import numpy as np
+
+    import yasph2d_amd as y
+
+    def run(sync):
+        w = y.FluidParticleWorld()
+        w.reset_fluid(1.0)
+        t = y.TimeManager()
+        s = y.DFSPHSolver(w)
+        for _ in range(25):
+            s.simulation_step(w, t, sync_world=sync)
+        w.add_fluid_rect(1.2, 1.0, 0.2, 0.2, 0.05)  # appended behind the particles the device is working on
+        for _ in range(10):
+            s.simulation_step(w, t, sync_world=sync)
+        s.sync_world(w)
+        return w.positions, w.velocities, t.total_simulated_ns
+
+    pa, va, ta = run(True)
+    pb, vb, tb = run(False)
+    assert ta == tb and len(pa) == len(pb) > 4050
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb)
+    assert pa[:4050, 1].min() < 0.69, "the first block has been falling for 35 steps, not 10"

@@ -96,6 +96,7 @@ FluidParticleWorld::FluidParticleWorld(Real smoothing_factor, Real particle_dens
 void FluidParticleWorld::remove_all_fluid_particles() {  // :129-132
     particles.positions.clear();
     particles.velocities.clear();
+    stale_prefix = 0;
     fluid_generation++;
 }
 void FluidParticleWorld::remove_all_boundary_particles() {  // :134-137 (the reference also clears velocities here)
@@ -268,6 +269,20 @@ void HipDfsphSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {  
     if (n != uploaded_n_ || w.fluid_generation != uploaded_generation_) {
         // The reference reads the world's Vecs directly; here they are (re)uploaded when the caller edited them.
         if (w.particles.velocities.size() != n) w.particles.velocities.resize(n, Vector{0, 0});
+        if (w.stale_prefix) {
+            // the caller edited a world whose first stale_prefix particles are behind the device (headless steps): fetch them first,
+            // so that e.g. add_fluid_rect mid-run appends to the CURRENT fluid instead of rewinding it to the last sync
+            const size_t keep = w.stale_prefix;
+            if (keep > n || keep != sphx_num_particles(ctx_)) {
+                last_status = SPHX_ERR_NOT_READY;
+                last_error = "the host world was edited while it was behind the device state: call sync_world() before editing particles";
+                return;
+            }
+            w.particles.densities.resize(n, 0.0f);
+            if ((rc = sphx_download(ctx_, &w.particles.positions[0].x, &w.particles.velocities[0].x, w.particles.densities.data(), nullptr)))
+                return fail(rc);
+            w.stale_prefix = 0;
+        }
         if ((rc = sphx_upload(ctx_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr, (uint32_t)n)))
             return fail(rc);
         uploaded_n_ = n;
@@ -277,6 +292,8 @@ void HipDfsphSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {  
     last_status = SPHX_OK;
     if (sync_every_step) {
         if ((rc = sync_world(w))) return fail(rc);
+    } else {
+        w.stale_prefix = n;  // the host arrays are now behind the device
     }
 }
 
@@ -312,6 +329,7 @@ int HipDfsphSolver::sync_world(FluidParticleWorld& w) {
     int rc = sphx_download(ctx_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr,
                            n ? w.particles.densities.data() : nullptr, n ? w.particles.particle_ids.data() : nullptr);
     // host arrays now equal the device state: no re-upload needed
+    w.stale_prefix = 0;
     uploaded_generation_ = w.fluid_generation;
     uploaded_n_ = n;
     return rc;
@@ -379,6 +397,7 @@ void sphx_world_set_particles(sphx_world* w, const float* pos_xy, const float* v
         p.positions[i] = sph::Point{pos_xy[2 * i], pos_xy[2 * i + 1]};
         p.velocities[i] = vel_xy ? sph::Vector{vel_xy[2 * i], vel_xy[2 * i + 1]} : sph::Vector{0, 0};
     }
+    w->w.stale_prefix = 0;  // everything replaced
     w->w.fluid_generation++;
 }
 void sphx_world_set_boundary(sphx_world* w, const float* xy, uint32_t n) {
@@ -423,6 +442,7 @@ int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sph
 }
 int sphx_solver_create_wcsph(const sphx_world* w, const sphx_params* params, sphx_solver** out) {
     if (!w || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
     sphx_solver* s = new sphx_solver(new sph::HipWcsphSolver(w->w, params));
     if (!s->s.ok()) {
         const int rc = s->s.last_status;

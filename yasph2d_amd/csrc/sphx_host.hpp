@@ -61,6 +61,11 @@ struct FluidParticleWorld {
     Vector gravity;
     bool boundary_changed;
     uint64_t fluid_generation = 1;  // bumped whenever the host arrays are edited by the caller
+    // Headless stepping (sync_world = 0) leaves the first `stale_prefix` host particles behind the device state.  The reference's
+    // caller always sees a current world (the solver works on its Vecs in place), so an edit that KEEPS those particles — appending
+    // with add_fluid_rect — must not rewind them: the solver downloads the prefix before it uploads the edited arrays.  Edits that
+    // replace everything (remove_all_fluid_particles, sphx_world_set_particles) reset it.
+    size_t stale_prefix = 0;
 
     FluidParticleWorld(Real smoothing_factor, Real particle_density, Real fluid_density);
     void remove_all_fluid_particles();

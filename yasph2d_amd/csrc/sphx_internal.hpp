@@ -38,6 +38,7 @@ constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered
 constexpr uint32_t DIR_STATIC = 1u;  // dynamic directory only: the boundary's directory covers this block too (offsets are multiples of 4096)
 constexpr uint32_t DIR_FLAGS = DIR_FRINGE | DIR_STATIC;
 enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u };
+constexpr uint32_t LOOP_HIST = 512;  // residual sums of the latest solver loop kept in the mailbox (ring; the reference caps a loop at 200 / 400 (+1) iterations)
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
 constexpr uint32_t MAX_TILE_PEERS = 8;  // a rectangle has at most 8 neighbours (4 edges + 4 corners) in a regular tiling
@@ -94,7 +95,8 @@ struct DevScalars {
     uint32_t ticket;       // second-level arrival counter (one arrival per stripe); reset by the last arriver
     uint32_t sort_total;   // number of particles that received a cell in the latest histogram scan (tile mode: new local count)
     float dt;              // time step the device derived from vmax with the host's timer law (sphx_step_begin_law)
-    uint32_t pad[28];
+    uint32_t loop_done;    // solver loop run by the device (LoopArgs): 0 while it iterates, else the iteration that met the residual test
+    uint32_t pad[27];
     Stripe stripe[STRIPES];
 };
 
@@ -110,6 +112,25 @@ struct Mailbox {
     uint32_t sort_total;
     uint32_t dt_bits;       // sphx_step_begin_law: the device's dt (float bits) ...
     unsigned long long dt_ns;  // ... and the Duration it came from
+    // solver loop terminated by the device (LoopArgs): written by the iteration that met the residual test, BEFORE its seq
+    volatile uint32_t loop_gen_done;  // generation number of the loop that has finished
+    uint32_t loop_iters;              // ... after this many iterations
+    double loop_hist[LOOP_HIST];      // residual sum of iteration k of the running loop at [k % LOOP_HIST] (the host re-derives every decision)
+};
+
+// A solver loop (dfsph.rs:195-247 / :346-402) whose termination test runs on the device: the last workgroup of compute_error
+// holds the residual sum, applies dfsph.rs:221-236 / :376-391 to it and records the outcome in DevScalars::loop_done; iterations
+// queued behind the terminating one return at once, and the density correction of the terminating iteration (it knows it is the
+// last) does the re-grid's advection + cell count.  The host verifies every decision from loop_hist afterwards.
+struct LoopArgs {
+    uint32_t enabled;    // 0: host-driven loop (tile mode: the residual needs an all-reduce over the ranks)
+    uint32_t iter;       // 1-based index of this iteration
+    uint32_t fixed;      // sphx_params.fixed_*_iterations
+    uint32_t max_iters;  // dfsph.rs:50 / :54
+    uint32_t gen;        // generation number of this loop
+    uint32_t n_total;    // particles the average runs over
+    float tol;           // dfsph.rs:49 / :53
+    float rho0;
 };
 
 // TimeManager::update_simulation_step (timemanager.rs:252-279) as the device applies it to its own vmax
@@ -191,6 +212,10 @@ struct sphx_ctx {
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
+    uint32_t pre_gen = 0;     // ... and their loop generation
+    uint32_t pre_queued = 0;  // density iterations sphx_step_begin_law has put on the stream (device-run loop)
+    uint32_t loop_gen = 0;    // generation counter of the device-run solver loops
+    int host_loop = 0;        // SPHX_HOST_LOOP=1: the host judges every residual (round-1 behaviour; A/B runs)
     std::string prof_filter;  // sphx_profile_filter: only launches with this label are timed, every prof_every-th of them
     uint32_t prof_every = 1, prof_counter = 0;
     bool external_stream = false;

@@ -1410,7 +1410,9 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
                                                         DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq,
-                                                        const float* __restrict__ dt_dev) {
+                                                        const float* __restrict__ dt_dev, LoopArgs la) {
+    // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
+    if (la.enabled && la.iter > 1u && scal->loop_done != 0u) return;
     if (dt_dev) dt = *dt_dev;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     float e = 0.0f, e_owned = 0.0f;
@@ -1454,7 +1456,31 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
         for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256)
             s += __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         s = block_sum_f64(s);
-        if (threadIdx.x == 0) mb->err_sum = s;
+        if (threadIdx.x == 0) {
+            mb->err_sum = s;
+            if (la.enabled) {
+                // dfsph.rs:221-236 / :376-391 on the spot, in the host's operations (f64 sum rounded once, two f32 divisions, one product)
+                mb->loop_hist[la.iter % LOOP_HIST] = s;
+                const float sum = (float)s;
+                const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
+                bool more;
+                if (!(fabsf(avg) <= 3.402823466e38f)) {
+                    more = false;  // not finite: the reference panics (dfsph.rs:223 / :378); the host reports it from loop_hist
+                } else if (la.fixed) {
+                    more = la.iter < la.fixed;
+                } else {
+                    const float rel = DIVERGENCE ? avg : avg / la.rho0;  // dfsph.rs:222
+                    more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
+                    if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
+                }
+                __hip_atomic_store(&scal->loop_done, more ? 0u : la.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!more) {
+                    mb->loop_iters = la.iter;
+                    __threadfence_system();
+                    __hip_atomic_store((uint32_t*)&mb->loop_gen_done, la.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
         publish_common(scal, mb, seq);
     }
 }
@@ -1467,7 +1493,9 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // The LAST density correction of a step leaves the final predicted velocity of its particle in registers: that is all the
 // advection + cell count of the re-grid that follows (k_key_count<true>) needs, so the correction does it on the spot and the
 // re-grid starts at the scan.  Whether a correction is the last one is only known afterwards (the residual decides): every density
-// correction counts, and the host clears the histogram again when another iteration follows.  hist == nullptr: plain correction.
+// correction counts, and the host clears the histogram again when another iteration follows — unless the loop is run by the device
+// (LoopArgs): then the correction knows from its own compute_error whether it is the last one, and only the last one counts.
+// hist == nullptr: plain correction.
 struct CountArgs {
     GridView g;
     uint32_t *hist, *cidx, *slot;
@@ -1476,7 +1504,10 @@ struct CountArgs {
 template <bool WARM, bool INV_DT>
 __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
-                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal) {
+                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la) {
+    // device-run loop: loop_done was settled by this iteration's compute_error (0: more follow; == iter: this is the last one)
+    const uint32_t done = la.enabled ? scal->loop_done : 0u;
+    if (done != 0u && done < la.iter) return;
     float dt = ca.dt;
     if (dt_dev) {
         dt = *dt_dev;
@@ -1532,7 +1563,7 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
     if (!WARM && INV_DT)
-        if (ca.hist) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
+        if (ca.hist && (!la.enabled || done == la.iter)) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
