@@ -73,10 +73,12 @@ typedef struct sphx_params {
     uint32_t fixed_density_iterations; /* 0 = adaptive (reference behaviour); >0 = run exactly this many (parity/bench mode) */
     uint32_t fixed_divergence_iterations;
     int32_t device;                    /* HIP device ordinal */
-    uint32_t list_span_limit;          /* neighbour-list compression (neighborhood_search.rs:262-273, README.md:12 "WIP"): a wave of 64
-                                          particles whose 3x3-cell candidates all lie within this many sorted slots stores 16-bit offsets
-                                          instead of 32-bit indices.  0 = default (65536); SPHX_LISTS_32BIT = never compress; smaller
-                                          values only make more waves fall back to 32 bit (test aid).  Results never depend on it. */
+    uint32_t list_span_limit;          /* neighbour-list layout (neighborhood_search.rs:262-273, README.md:12 "WIP"): lists are local to a
+                                          workgroup of 256 Morton-consecutive particles — 16-bit slots of the record window the traversal
+                                          kernels stage in LDS, plus a per-workgroup table of at most this many out-of-window neighbour
+                                          entries.  0 = default (512, the table's capacity); SPHX_LISTS_32BIT = 32-bit global indices
+                                          everywhere (traversals gather from global memory); smaller values only put more workgroups on
+                                          that fallback (test aid).  Results never depend on it. */
     uint32_t reserved[3];
 } sphx_params;
 #define SPHX_LISTS_32BIT 0xFFFFFFFFu

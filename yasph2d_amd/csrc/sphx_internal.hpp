@@ -31,6 +31,17 @@ constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 thre
 #endif
 constexpr uint32_t STAGE_ROWS = SPHX_STAGE_ROWS;     // neighbour rows staged in LDS per wave before the coalesced row store
 constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions of [block_first - 256, block_last + 256] are staged in LDS
+#ifndef SPHX_LIST_HALO
+#define SPHX_LIST_HALO 128
+#endif
+// Neighbour lists are WORKGROUP-LOCAL: the traversal kernels stage the records of the sorted slots
+// [block_first - LIST_HALO, block_last + LIST_HALO] in LDS with coalesced loads; a list entry < LIST_WIN is a slot of that window,
+// an entry >= LIST_WIN indexes the workgroup's table of out-of-window neighbours (REMOTE_CAP global record indices, staged behind
+// the window).  Every neighbour record is then read from LDS.
+constexpr uint32_t LIST_HALO = SPHX_LIST_HALO;
+constexpr uint32_t LIST_WIN = 256 + 2 * LIST_HALO;
+constexpr uint32_t REMOTE_CAP = 512;
+constexpr uint32_t RC_WIDE = 0xFFFFFFFFu;  // rcount marker: this workgroup's lists hold 32-bit global record indices (no staging)
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
@@ -61,16 +72,18 @@ struct Consts {
     // spatial tile owned by this context (multi-GPU): the cell rectangle [x0,x1) x [y0,y1); reductions only count owned
     // particles.  Single-GPU default: the whole domain.
     TileRect tile;
-    // a wave whose lanes' candidate index spans all stay <= span_limit stores 16-bit list entries (65536; 0 forces 32-bit lists)
-    uint32_t span_limit;
+    // a workgroup with at most remote_cap out-of-window neighbour entries stores workgroup-local 16-bit lists (<= REMOTE_CAP;
+    // 0 forces 32-bit global lists)
+    uint32_t remote_cap;
 };
 
 // wave-sliced ELL neighbour lists: entry k of particle i; counts[i] = format<<31 | count_total<<16 | count_dynamic;
-// bases[i >> 6] = {smallest dynamic entry, soff + smallest static entry} of the 64-particle slice (16-bit format only)
+// rcount[i >> 8] = number of entries of the workgroup's out-of-window table remote[(i >> 8) * REMOTE_CAP ..], or RC_WIDE
 struct NbView {
     const uint32_t* list;
     const uint32_t* counts;
-    const uint2* bases;
+    const uint32_t* rcount;
+    const uint32_t* remote;
 };
 
 // Two-level Morton cell grid.  dir[] is a small host-built 2D directory over the 64x64-cell blocks of the
@@ -87,8 +100,9 @@ struct GridView {
 struct alignas(128) Stripe {
     unsigned long long nb_entries;  // partial sum of count_total over ALL builds so far (stats only; the host takes differences)
     unsigned long long owned;       // partial count of owned particles over ALL tile re-grids so far (host takes differences)
+    unsigned long long rem_entries; // partial sum of out-of-window list entries over ALL builds so far (stats only)
     uint32_t ticket;                // first-level arrival counter of the last-block reductions
-    uint32_t pad[27];
+    uint32_t pad[25];
 };
 struct DevScalars {
     uint32_t flags;        // DF_*
@@ -109,6 +123,7 @@ struct Mailbox {
     double err_sum;         // residual sum of the last compute_error launch
     unsigned long long nb_entries;
     unsigned long long owned_cum;
+    unsigned long long rem_entries;
     uint32_t sort_total;
     uint32_t dt_bits;       // sphx_step_begin_law: the device's dt (float bits) ...
     unsigned long long dt_ns;  // ... and the Duration it came from
@@ -208,7 +223,8 @@ struct sphx_ctx {
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
     uint32_t* nb_counts = nullptr;  // format << 31 | count_total << 16 | count_dynamic
-    uint2* nb_bases = nullptr;
+    uint32_t* nb_rcount = nullptr;  // per 256-particle workgroup: entries in its out-of-window table, or RC_WIDE
+    uint32_t* nb_remote = nullptr;  // per workgroup REMOTE_CAP global record indices
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
@@ -228,7 +244,7 @@ struct sphx_ctx {
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;
-    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_bases}; }
+    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_rcount, nb_remote}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;
@@ -246,6 +262,7 @@ struct sphx_ctx {
     sphx::Mailbox* mbox_dev = nullptr;  // its device address
     uint32_t seq = 0;
     unsigned long long nb_cum = 0, nb_last = 0;  // cumulative neighbour-entry counter seen so far / entries of the last build
+    unsigned long long rem_cum = 0, rem_last = 0;  // the same for out-of-window entries
     unsigned long long owned_cum = 0, owned_last = 0, owned_base = 0;  // cumulative owned counter (host copy), last re-grid's count
     bool owned_dirty = false;  // a tile re-grid ran: the next iteration's publish carries its owned count
     // tile mode (multi-GPU spatial decomposition)

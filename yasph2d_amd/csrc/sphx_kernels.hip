@@ -183,17 +183,20 @@ __device__ __forceinline__ bool arrive_is_last(DevScalars* scal) {  // call from
 __device__ __forceinline__ void publish_common(DevScalars* scal, Mailbox* mb, uint32_t seq) {
     static_assert(STRIPES <= 64, "one lane per stripe");
     if (threadIdx.x >= 64) return;
-    unsigned long long nb = 0, ow = 0;
+    unsigned long long nb = 0, ow = 0, rm = 0;
     if (threadIdx.x < STRIPES) {
         nb = __hip_atomic_load(&scal->stripe[threadIdx.x].nb_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ow = __hip_atomic_load(&scal->stripe[threadIdx.x].owned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rm = __hip_atomic_load(&scal->stripe[threadIdx.x].rem_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         nb += __shfl_down(nb, d, 64);
         ow += __shfl_down(ow, d, 64);
+        rm += __shfl_down(rm, d, 64);
     }
     if (threadIdx.x == 0) {
+        mb->rem_entries = rm;
         mb->owned_cum = ow;
         mb->sort_total = __hip_atomic_load(&scal->sort_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mb->nb_entries = nb;
@@ -896,8 +899,8 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 template <bool FUSE>
 __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
-                                                         uint2* __restrict__ bases, float* __restrict__ density, float* __restrict__ alpha,
-                                                         DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
+                                                         uint32_t* __restrict__ rcount, uint32_t* __restrict__ remote, float* __restrict__ density,
+                                                         float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
     __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
@@ -913,8 +916,6 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
     __syncthreads();
     uint32_t cd = 0, ct = 0;
-    uint32_t wide = 0, lo_d = 0, lo_s = 0;  // list format of this wave (see NbHead), bases of the 16-bit offsets
-    uint16_t* const lp16 = (uint16_t*)(list + (size_t)(i >> 6) * 4096) + lane;
     float2 pi = make_float2(0.0f, 0.0f);
     if (i < n) {
         pi = lds_read_f2(&win[i - w0]);
@@ -976,6 +977,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
         // (cx, cy pass through an opaque asm so that the compiler recomputes the nine local offsets here instead of keeping them alive
         // — spilled — across the whole candidate section for a block that most waves never enter)
+        // Staged / stored value of a static neighbour: its slot in the [N|B] record arrays, soff + j.
         uint32_t cxs = cx, cys = cy;
         asm volatile("" : "+v"(cxs), "+v"(cys));
         if (__any(maybe_static) && __any(slots9(gs, cxs, cys, slot))) {
@@ -990,9 +992,9 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
                     if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
                     if (ct < MAX_NEIGHBORS) {
                         if (ct < STAGE_ROWS)
-                            mytile[ct * 64] = j;
+                            mytile[ct * 64] = soff + j;
                         else
-                            list[ell_index(i, ct)] = j;
+                            list[ell_index(i, ct)] = soff + j;
                         ct += 1;
                     }
                 }
@@ -1000,42 +1002,70 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         }
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
-        // List format of the staged rows (NbHead): entries ascend, so the first and the last staged entry of each part bound every
-        // lane's range.  Own column of the tile, written by this lane: no barrier needed.
-        uint32_t first_d = 0xFFFFFFFFu, last_d = 0, first_s = 0xFFFFFFFFu, last_s = 0;
-        if (cd) {
-            first_d = mytile[0];
-            last_d = mytile[(min(cd, STAGE_ROWS) - 1u) * 64];
-        }
-        if (ct > cd && cd < STAGE_ROWS) {
-            first_s = mytile[cd * 64];
-            last_s = mytile[(min(ct, STAGE_ROWS) - 1u) * 64];
-        }
-        // ONE base pair per wave (the smallest dynamic / static entry of its 64 particles), kept per 64-particle slice: a scalar
-        // load for the readers instead of 8 bytes per particle and traversal
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            first_d = min(first_d, (uint32_t)__shfl_xor((int)first_d, d, 64));
-            first_s = min(first_s, (uint32_t)__shfl_xor((int)first_s, d, 64));
-        }
-        lo_d = first_d == 0xFFFFFFFFu ? 0u : first_d;
-        lo_s = first_s == 0xFFFFFFFFu ? 0u : first_s;
-        const uint32_t far = (cd ? last_d - lo_d : 0u) | ((ct > cd && cd < STAGE_ROWS) ? last_s - lo_s : 0u);
-        wide = __any(far >= K.span_limit) ? 1u : 0u;
-        counts[i] = (wide << 31) | (ct << 16) | cd;
-        if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) bases[i >> 6] = make_uint2(lo_d, soff + lo_s);
         if (flags) atomicOr(&scal->flags, flags);
     }
-    // staged rows -> global, one coalesced row per store (lanes past their own count write don't-care values)
+    // ---- list format of this workgroup (NbHead) ------------------------------------------------------------------------------
+    // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
+    // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
+    // away in Morton order, or a boundary particle) gets the next free line r of this workgroup's out-of-window table and is stored
+    // as LIST_WIN + r.  Lines are handed out in a fixed order (wave, row, lane).  A workgroup with more than remote_cap such
+    // entries keeps 32-bit global slots (RC_WIDE; its traversals gather from global memory).
+    __shared__ uint32_t wtot[4];
+    const uint32_t lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
+    const uint32_t lwlen = min(b0 + 256u + LIST_HALO, n) - lw0;
     uint32_t m = min(ct, STAGE_ROWS);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    wide = __builtin_amdgcn_readfirstlane(wide);  // lane 0 took part above whenever any lane of the wave did
+    const bool spill = __any(ct > STAGE_ROWS);
+    // pass A: count the out-of-window entries
+    uint32_t wave_rem = 0, spill_rem = 0;
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t g = lds_read_u32(&tile[w][k][lane]);
+        wave_rem += (uint32_t)__popcll(__ballot(k < ct && g - lw0 >= lwlen));
+    }
+    uint32_t spill_before = 0;  // out-of-window spill entries of lower lanes
+    if (spill) {
+        for (uint32_t k = STAGE_ROWS; k < ct; ++k) spill_rem += (list[ell_index(i, k)] - lw0 >= lwlen) ? 1u : 0u;
+        const uint32_t inc = wave_incl_scan(spill_rem);
+        spill_before = inc - spill_rem;
+        wave_rem += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    if (lane == 0) wtot[w] = wave_rem;
+    __syncthreads();
+    const uint32_t rtot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    uint32_t run = (w > 0 ? wtot[0] : 0u) + (w > 1 ? wtot[1] : 0u) + (w > 2 ? wtot[2] : 0u);
+    const bool wide = rtot > K.remote_cap || K.remote_cap == 0u;
+    uint32_t* const rtab = remote + (size_t)xcd_bid() * REMOTE_CAP;
+    if (i < n) counts[i] = ((wide ? 1u : 0u) << 31) | (ct << 16) | cd;
+    if (threadIdx.x == 0) rcount[xcd_bid()] = wide ? RC_WIDE : rtot;
+    // pass B: rows out, one coalesced row per store (lanes past their own count write don't-care values)
     if (wide) {
         const size_t row0 = (size_t)(i >> 6) * 64;
-        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = tile[w][k][lane];
+        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = lds_read_u32(&tile[w][k][lane]);
     } else {
-        for (uint32_t k = 0; k < m; ++k) lp16[k * 64] = (uint16_t)(tile[w][k][lane] - (k < cd ? lo_d : lo_s));
+        uint16_t* const lp16 = (uint16_t*)(list + (size_t)(i >> 6) * 4096) + lane;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t g = lds_read_u32(&tile[w][k][lane]);
+            const bool rem = k < ct && g - lw0 >= lwlen;
+            const unsigned long long mask = __ballot(rem);
+            const uint32_t r = run + (uint32_t)__popcll(mask & below);
+            run += (uint32_t)__popcll(mask);
+            if (rem) rtab[r] = g;
+            lp16[k * 64] = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
+        }
+        if (spill) {
+            // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their RC_WIDE address); the
+            // 16-bit row k lies below every 32-bit row >= k, so rewriting in ascending k never overwrites an entry still to be read
+            uint32_t r = run + spill_before;
+            for (uint32_t k = STAGE_ROWS; k < ct; ++k) {
+                const uint32_t g = list[ell_index(i, k)];
+                const bool rem = g - lw0 >= lwlen;
+                if (rem) rtab[r] = g;
+                lp16[k * 64] = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
+                r += rem ? 1u : 0u;
+            }
+        }
     }
 
     if (FUSE && i < n) {
@@ -1045,14 +1075,9 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         for (uint32_t k = 0; k < ct; ++k) {
             uint32_t j = lds_read_u32(&tile[w][min(k, STAGE_ROWS - 1u)][lane]);
             if (k >= STAGE_ROWS) j = list[ell_index(i, k)];
-            float2 rj;
-            if (k < cd) {
-                const uint32_t wj = j - w0;
-                rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
-                if (wj >= wlen) rj = gat(posA, j);
-            } else {
-                rj = gat(posA, soff + j);
-            }
+            const uint32_t wj = j - w0;  // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
+            float2 rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
+            if (wj >= wlen) rj = gat(posA, j);
             const float dx = rj.x - pi.x, dy = rj.y - pi.y;
             const float r = sqrt_dist(dx * dx + dy * dy);
             const float q = fminf(r * K.w_hinv, 1.0f);
@@ -1068,7 +1093,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
         alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
     }
-    // total number of list entries (stats only): block reduce, one striped atomic per workgroup
+    // total number of list entries and of out-of-window entries (stats only): block reduce, striped atomics per workgroup
     unsigned long long tot = ct;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) tot += __shfl_down(tot, d, 64);
@@ -1078,12 +1103,19 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     if (threadIdx.x == 0) {
         const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];
         if (t) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, t);
+        if (rtot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// neighbour traversal: loads are issued in batches of NB_BATCH (indices, then records) so several gathers are in flight per
-// lane; the accumulation stays sequential in list order.
+// neighbour traversal.  Lists are WORKGROUP-LOCAL (neighborhood_search.rs:262-273 only sketches a compressed layout; README.md:12
+// calls it WIP): the 256 particles of a workgroup look at neighbours that sit, in Morton order, almost always within a few hundred
+// sorted slots of them.  A traversal kernel stages the records of the window [lw0, lw0 + lwlen) and the (few) records named by the
+// workgroup's out-of-window table in LDS with COALESCED loads, and the 16-bit list entries are slots of that staging area: every
+// neighbour record is an LDS read.  (Gathering 16-byte records straight from global memory costs one L1 tag lookup per lane and
+// neighbour; the kernels were bound by exactly that.)  A workgroup whose out-of-window table would overflow keeps 32-bit global
+// slots and gathers from global memory (RC_WIDE, bit 31 of its count words) — results never depend on the format.
+// The accumulation stays sequential in list order inside one lane.
 // ------------------------------------------------------------------------------------------------------------------
 #ifndef TRAV_BOUNDS
 #define TRAV_BOUNDS __launch_bounds__(256)
@@ -1091,19 +1123,55 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
 #ifndef NB_BATCH
 #define NB_BATCH 4
 #endif
+constexpr uint32_t STAGE_SLOTS = LIST_WIN + REMOTE_CAP;
 
-// Compressed lists (neighborhood_search.rs:262-273 sketches the idea; README.md:12 calls it WIP).  The entries of one particle
-// are ascending sorted-array indices out of its 3x3 cell box, so they sit within a short span above the first candidate: a
-// wave whose 64 particles all span < 65536 slots stores rows 0..STAGE_ROWS-1 (the rows staged in LDS by the build) as 16-bit
-// offsets from a per-wave base pair (128-byte rows instead of 256), any other wave keeps 32-bit rows; rows >= STAGE_ROWS are
-// always 32-bit (they lie behind the 16-bit rows of the slice).  The format bit is wave-uniform (bit 31 of every lane's count word).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_cu128;
+__device__ __forceinline__ float4 lds_read_f4(const float4* p) {
+    const u32x4_t v = *(lds_cu128*)p;
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
+
+// Geometry of a workgroup's staging area; identical in the build and in every traversal kernel.
+struct NbStage {
+    uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
+    uint32_t R;           // entries of the out-of-window table (0 when wide)
+    bool wide;            // RC_WIDE: lists hold global slots, nothing is staged
+    const uint32_t* rtab;
+};
+__device__ __forceinline__ NbStage nb_stage_of(const NbView& nb, uint32_t blk, uint32_t n) {
+    NbStage S;
+    const uint32_t b0 = blk * 256u;
+    S.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
+    S.lwlen = b0 < n ? min(b0 + 256u + LIST_HALO, n) - S.lw0 : 0u;
+    const uint32_t rc = b0 < n ? nb.rcount[blk] : 0u;  // workgroups past the last particle have no lists
+    S.wide = rc == RC_WIDE;
+    S.R = S.wide ? 0u : min(rc, REMOTE_CAP);
+    if (S.wide) S.lwlen = 0u;
+    S.rtab = nb.remote + (size_t)blk * REMOTE_CAP;
+    return S;
+}
+// rec[0 .. lwlen) = src[lw0 ..]; rec[LIST_WIN + r] = src[rtab[r]] (zero for table entries >= limit: arrays without a boundary tail).
+// Called by all threads of the workgroup; the caller places the barrier.
+template <class T>
+__device__ __forceinline__ void nb_stage_load(T* rec, const T* __restrict__ src, const NbStage& S, uint32_t limit) {
+    for (uint32_t t = threadIdx.x; t < S.lwlen; t += 256) rec[t] = src[S.lw0 + t];
+    for (uint32_t t = threadIdx.x; t < S.R; t += 256) {
+        const uint32_t g = S.rtab[t];
+        T v{};
+        if (g < limit) v = gat(src, g);
+        rec[LIST_WIN + t] = v;
+    }
+}
+
 struct NbHead {
-    uint32_t cd, ct, base_d, base_s, soff;
+    uint32_t cd, ct;
     bool wide;
     const char* rows;  // this wave's 16 KiB slice of the list buffer (wave-uniform: scalar base + 32-bit lane offsets)
     uint32_t lane;
 };
-__device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t soff) {
+__device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i) {
     NbHead h;
     const uint32_t c = nb.counts[i];
     h.cd = c & 0xffffu;
@@ -1111,48 +1179,36 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i, uint32_t
     h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     h.lane = i & 63u;
-    h.soff = soff;
-    const uint2 b = nb.bases[__builtin_amdgcn_readfirstlane(i >> 6)];  // one pair per 64-particle slice: a scalar load
-    h.base_d = h.wide ? 0u : b.x;
-    h.base_s = h.wide ? soff : b.y;
     return h;
 }
-// Record indices ([N|B] slot) of entries k0 .. k0+NB_BATCH-1 (k0 < lim).  Entries past the end repeat entry lim-1, so every
-// load of a batch is unconditional — no branch per entry, all gathers of a batch in flight together; the callers discard the
-// padded terms with a select.
+// Entries k0 .. k0+NB_BATCH-1 (k0 < lim): staging slots (16-bit rows) or global slots (32-bit rows, WIDE).  Entries past the end
+// repeat entry lim-1, so every load of a batch is unconditional — no branch per entry; the callers discard the padded terms with a
+// select.
+template <bool WIDE>
 __device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t lim, uint32_t (&j)[NB_BATCH]) {
-    static_assert(STAGE_ROWS % NB_BATCH == 0, "a batch never straddles the 16-bit / 32-bit rows");
-    const bool w32 = h.wide || k0 >= STAGE_ROWS;
     const uint32_t last = lim - 1u;
-    uint32_t kk[NB_BATCH];
 #pragma unroll
-    for (int u = 0; u < NB_BATCH; ++u) kk[u] = min(k0 + u, last);
-    if (w32) {
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = *(const uint32_t*)(h.rows + (uint32_t)((kk[u] * 64u + h.lane) * 4u));
-    } else {
-#pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) j[u] = *(const uint16_t*)(h.rows + (uint32_t)((kk[u] * 64u + h.lane) * 2u));
+    for (int u = 0; u < NB_BATCH; ++u) {
+        const uint32_t kk = min(k0 + u, last);
+        if (WIDE)
+            j[u] = *(const uint32_t*)(h.rows + (uint32_t)((kk * 64u + h.lane) * 4u));
+        else
+            j[u] = *(const uint16_t*)(h.rows + (uint32_t)((kk * 64u + h.lane) * 2u));
     }
-    const uint32_t bd = w32 ? 0u : h.base_d, bs = w32 ? h.soff : h.base_s;
-#pragma unroll
-    for (int u = 0; u < NB_BATCH; ++u) j[u] += (kk[u] < h.cd) ? bd : bs;
 }
-
-// Software-pipelined traversal of entries 0..lim-1 in list order.  The kernels are bound by memory LATENCY (a wave spends ~70 %
-// of its life parked on s_waitcnt, profiles/), so the dependent chain index -> record is overlapped: the index loads of batch
-// b+1 are issued right after the record gathers of batch b, before those are consumed.
+// Software-pipelined traversal of entries 0..lim-1 in list order: the index loads of batch b+1 are issued right after the record
+// reads of batch b, before those are consumed.
 //   gather(slot) -> record (any type);   consume(record, k) must ignore k >= lim (padded entries repeat entry lim-1).
-template <class G, class C>
+template <bool WIDE, class G, class C>
 __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, G&& gather, C&& consume) {
     if (lim == 0) return;
     uint32_t jn[NB_BATCH];
-    nb_fetch(h, 0, lim, jn);
+    nb_fetch<WIDE>(h, 0, lim, jn);
     for (uint32_t k0 = 0; k0 < lim; k0 += NB_BATCH) {
         decltype(gather(0u)) r[NB_BATCH];
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) r[u] = gather(jn[u]);
-        nb_fetch(h, k0 + NB_BATCH, lim, jn);  // clamped to the last entry when the list ends here
+        nb_fetch<WIDE>(h, k0 + NB_BATCH, lim, jn);  // clamped to the last entry when the list ends here
 #pragma unroll
         for (int u = 0; u < NB_BATCH; ++u) consume(r[u], k0 + (uint32_t)u);
     }
@@ -1163,10 +1219,15 @@ __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, G&& g
 template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    __shared__ float2 rec[STAGE_SLOTS];
+    const uint32_t blk = xcd_bid();
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const NbStage S = nb_stage_of(nb, blk, n);
+    nb_stage_load(rec, posA, S, 0xFFFFFFFFu);
+    __syncthreads();
     if (i >= n) return;
-    const float2 ri = posA[i];
-    const NbHead h = nb_head(nb, i, soff);
+    const NbHead h = nb_head(nb, i);
+    const float2 ri = S.wide ? posA[i] : lds_read_f2(&rec[i - S.lw0]);
     const uint32_t ct = h.ct;
     float rho = 0.0f;
     if (DENSITY) {
@@ -1175,32 +1236,34 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
         if (KIND == 2) rho = spiky_eval(K, 0.0f) * K.mass;
     }
     float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-    nb_traverse(
-        h, ct, [&](uint32_t slot) { return gat(posA, slot); },
-        [&](float2 rj, uint32_t k) {
-            const bool live = k < ct;
-            const float dx = rj.x - ri.x, dy = rj.y - ri.y;
-            const float r_sq = dx * dx + dy * dy;
-            const float r = sqrt_dist(r_sq);
-            if (DENSITY) {
-                float wv;
-                if (KIND == 0) wv = wendland_eval(K, r);
-                if (KIND == 1) wv = poly6_eval(K, r_sq);
-                if (KIND == 2) wv = spiky_eval(K, r);
-                const float t = rho + wv * K.mass;
-                rho = live ? t : rho;
-            }
-            if (ALPHA) {
-                const float q = fminf(r * K.w_hinv, 1.0f);
-                const float omq = 1.0f - q;
-                const float sg = K.w_ngrad * omq * omq * omq;
-                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-                const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
-                gsx = live ? tx : gsx;
-                gsy = live ? ty : gsy;
-                gss = live ? ts : gss;
-            }
-        });
+    auto consume = [&](float2 rj, uint32_t k) {
+        const bool live = k < ct;
+        const float dx = rj.x - ri.x, dy = rj.y - ri.y;
+        const float r_sq = dx * dx + dy * dy;
+        const float r = sqrt_dist(r_sq);
+        if (DENSITY) {
+            float wv;
+            if (KIND == 0) wv = wendland_eval(K, r);
+            if (KIND == 1) wv = poly6_eval(K, r_sq);
+            if (KIND == 2) wv = spiky_eval(K, r);
+            const float t = rho + wv * K.mass;
+            rho = live ? t : rho;
+        }
+        if (ALPHA) {
+            const float q = fminf(r * K.w_hinv, 1.0f);
+            const float omq = 1.0f - q;
+            const float sg = K.w_ngrad * omq * omq * omq;
+            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+            const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
+            gsx = live ? tx : gsx;
+            gsy = live ? ty : gsy;
+            gss = live ? ts : gss;
+        }
+    };
+    if (S.wide)
+        nb_traverse<true>(h, ct, [&](uint32_t g) { return gat(posA, g); }, consume);
+    else
+        nb_traverse<false>(h, ct, [&](uint32_t slot) { return lds_read_f2(&rec[slot]); }, consume);
     if (DENSITY) density[i] = fmaxf(rho, K.rho0);                                  // fluidparticleworld.rs:229
     if (ALPHA) alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);     // dfsph.rs:94
 }
@@ -1275,14 +1338,21 @@ __device__ __forceinline__ void reduce_publish_vmax(float vsq, uint32_t* __restr
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, Consts K,
+__global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
                                                       Mailbox* __restrict__ mb, uint32_t seq, TimerLaw law) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    __shared__ float4 rec[STAGE_SLOTS];
+    __shared__ float rho_s[STAGE_SLOTS];
+    const uint32_t blk = xcd_bid();
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const NbStage S = nb_stage_of(nb, blk, n);
+    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
+    nb_stage_load(rho_s, density, S, soff);  // density[] has no boundary tail (XSPH runs over dynamic neighbours only, dfsph.rs:456)
+    __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = PV[i];
-        const NbHead h = nb_head(nb, i, 0u);
+        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
+        const NbHead h = nb_head(nb, i);
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
@@ -1290,16 +1360,18 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
             float4 pv;
             float rho;
         };
-        nb_traverse(
-            h, cd, [&](uint32_t slot) { return Rec{gat(PV, slot), gat(density, slot)}; },
-            [&](const Rec& r, uint32_t k) {
-                const float dx = r.pv.x - pvi.x, dy = r.pv.y - pvi.y;
-                const float r_sq = dx * dx + dy * dy;
-                const float f = em * poly6_eval(K, r_sq) / (r.rho * dt);
-                const float tx = ax + f * (r.pv.z - pvi.z), ty = ay + f * (r.pv.w - pvi.w);
-                ax = k < cd ? tx : ax;
-                ay = k < cd ? ty : ay;
-            });
+        auto consume = [&](const Rec& r, uint32_t k) {
+            const float dx = r.pv.x - pvi.x, dy = r.pv.y - pvi.y;
+            const float r_sq = dx * dx + dy * dy;
+            const float f = em * poly6_eval(K, r_sq) / (r.rho * dt);
+            const float tx = ax + f * (r.pv.z - pvi.z), ty = ay + f * (r.pv.w - pvi.w);
+            ax = k < cd ? tx : ax;
+            ay = k < cd ? ty : ay;
+        };
+        if (S.wide)
+            nb_traverse<true>(h, cd, [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g)}; }, consume);
+        else
+            nb_traverse<false>(h, cd, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
@@ -1356,12 +1428,19 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
 __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                           float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials,
                                           DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    __shared__ float4 rec[STAGE_SLOTS];
+    __shared__ float rho_s[STAGE_SLOTS];
+    const uint32_t blk = xcd_bid();
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const NbStage S = nb_stage_of(nb, blk, n);
+    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
+    nb_stage_load(rho_s, density, S, soff);  // density[] has no boundary tail; static entries do not use it
+    __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = PV[i];
+        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
         const float rhoi = density[i];
-        const NbHead h = nb_head(nb, i, soff);
+        const NbHead h = nb_head(nb, i);
         const uint32_t cd = h.cd, ct = h.ct;
         float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
         const float pi = wcsph_pressure(K, rhoi);
@@ -1369,31 +1448,33 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
             float4 pv;
             float rho;
         };
-        nb_traverse(
-            h, ct, [&](uint32_t slot) { return Rec{gat(PV, slot), gat(density, slot < soff ? slot : i)}; },  // density[] has no boundary tail
-            [&](const Rec& q, uint32_t k) {
-                const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
-                const float r_sq = dx * dx + dy * dy;
-                const float r = sqrt_dist(r_sq);
-                float tx, ty;
-                if (k < cd) {
-                    const float pj = wcsph_pressure(K, q.rho);
-                    const float pu = -K.mass * (pi + pj) / (2.0f * rhoi * q.rho);                   // wscsph.rs:99
-                    const float dd = fmaxf(K.sp_h - r, 0.0f);
-                    const float sg = K.sp_ngrad * dd * dd / (r + 1.0e-10f);                          // Spiky::gradient, spiky.rs:34-37
-                    tx = ax + pu * (sg * dx);
-                    ty = ay + pu * (sg * dy);
-                    const float f = K.xsph_eps * K.mass * poly6_eval(K, r_sq) / (q.rho * dt);        // xsph.rs:21-23
-                    tx = tx + f * (q.pv.z - pvi.z);
-                    ty = ty + f * (q.pv.w - pvi.w);
-                } else {
-                    const float s = K.wc_boundary_force * spiky_eval(K, r) / r_sq;                   // wscsph.rs:114
-                    tx = ax - s * dx;
-                    ty = ay - s * dy;
-                }
-                ax = k < ct ? tx : ax;
-                ay = k < ct ? ty : ay;
-            });
+        auto consume = [&](const Rec& q, uint32_t k) {
+            const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
+            const float r_sq = dx * dx + dy * dy;
+            const float r = sqrt_dist(r_sq);
+            float tx, ty;
+            if (k < cd) {
+                const float pj = wcsph_pressure(K, q.rho);
+                const float pu = -K.mass * (pi + pj) / (2.0f * rhoi * q.rho);                   // wscsph.rs:99
+                const float dd = fmaxf(K.sp_h - r, 0.0f);
+                const float sg = K.sp_ngrad * dd * dd / (r + 1.0e-10f);                          // Spiky::gradient, spiky.rs:34-37
+                tx = ax + pu * (sg * dx);
+                ty = ay + pu * (sg * dy);
+                const float f = K.xsph_eps * K.mass * poly6_eval(K, r_sq) / (q.rho * dt);        // xsph.rs:21-23
+                tx = tx + f * (q.pv.z - pvi.z);
+                ty = ty + f * (q.pv.w - pvi.w);
+            } else {
+                const float s = K.wc_boundary_force * spiky_eval(K, r) / r_sq;                   // wscsph.rs:114
+                tx = ax - s * dx;
+                ty = ay - s * dy;
+            }
+            ax = k < ct ? tx : ax;
+            ay = k < ct ? ty : ay;
+        };
+        if (S.wide)
+            nb_traverse<true>(h, ct, [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g < soff ? g : i)}; }, consume);
+        else
+            nb_traverse<false>(h, ct, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;
@@ -1414,24 +1495,31 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
     // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
     if (la.enabled && la.iter > 1u && scal->loop_done != 0u) return;
     if (dt_dev) dt = *dt_dev;
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    __shared__ float4 rec[STAGE_SLOTS];
+    const uint32_t blk = xcd_bid();
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const NbStage S = nb_stage_of(nb, blk, n);
+    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
+    __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
-        const NbHead h = nb_head(nb, i, soff);
+        const NbHead h = nb_head(nb, i);
         const uint32_t ct = h.ct;
-        const float4 pvi = PV[i];
+        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
-            nb_traverse(
-                h, ct, [&](uint32_t slot) { return gat(PV, slot); },
-                [&](const float4& r, uint32_t k) {
-                    const float2 g = wendland_grad(K, ri, make_float2(r.x, r.y));
-                    // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
-                    const float dvx = pvi.z - r.z, dvy = pvi.w - r.w;
-                    const float t = delta + (dvx * g.x + dvy * g.y);
-                    delta = k < ct ? t : delta;
-                });
+            auto consume = [&](const float4& r, uint32_t k) {
+                const float2 g = wendland_grad(K, ri, make_float2(r.x, r.y));
+                // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
+                const float dvx = pvi.z - r.z, dvy = pvi.w - r.w;
+                const float t = delta + (dvx * g.x + dvy * g.y);
+                delta = k < ct ? t : delta;
+            };
+            if (S.wide)
+                nb_traverse<true>(h, ct, [&](uint32_t g) { return gat(PV, g); }, consume);
+            else
+                nb_traverse<false>(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, consume);
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
@@ -1513,10 +1601,18 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         dt = *dt_dev;
         inv_dt = 1.0f / dt;
     }
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    // staged neighbour records: WARM: {pos, v*} (+ the warm-start value of the neighbour); else PK = {pos, k, err}
+    __shared__ float4 rec[STAGE_SLOTS];
+    __shared__ float warm_s[WARM ? STAGE_SLOTS : 1];
+    const uint32_t blk = xcd_bid();
+    const uint32_t i = blk * 256 + threadIdx.x;
+    const NbStage S = nb_stage_of(nb, blk, n);
+    nb_stage_load(rec, WARM ? (const float4*)PV : PK, S, 0xFFFFFFFFu);
+    if (WARM) nb_stage_load(warm_s, (const float*)warm, S, soff);  // warm[] has no boundary tail; static entries do not use it
+    __syncthreads();
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
-        const NbHead h = nb_head(nb, i, soff);
+        const NbHead h = nb_head(nb, i);
         const uint32_t cd = h.cd, ct = h.ct;
         const float4 pvi = PV[i];
         float ki;
@@ -1525,7 +1621,7 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             ki = 0.5f * fmaxf(warm[i], lim);
             ri = make_float2(pvi.x, pvi.y);
         } else {
-            const float4 pki = PK[i];
+            const float4 pki = S.wide ? PK[i] : lds_read_f4(&rec[i - S.lw0]);
             ki = pki.z;
             ri = make_float2(pki.x, pki.y);
         }
@@ -1534,22 +1630,32 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             float4 r;
             float w;
         };
-        nb_traverse(
-            h, ct,
-            [&](uint32_t slot) {
-                // warm[] has no boundary tail; static entries do not use it
-                if (WARM) return Rec{gat((const float4*)PV, slot), gat((const float*)warm, slot < soff ? slot : i)};
-                return Rec{gat(PK, slot), 0.0f};
-            },
-            [&](const Rec& q, uint32_t k) {
-                const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
-                // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
-                const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
-                const float s = k < cd ? ki + kj : ki;
-                const float tx = dx + s * g.x, ty = dy + s * g.y;
-                dx = k < ct ? tx : dx;
-                dy = k < ct ? ty : dy;
-            });
+        auto consume = [&](const Rec& q, uint32_t k) {
+            const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
+            // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
+            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
+            const float s = k < cd ? ki + kj : ki;
+            const float tx = dx + s * g.x, ty = dy + s * g.y;
+            dx = k < ct ? tx : dx;
+            dy = k < ct ? ty : dy;
+        };
+        if (S.wide)
+            nb_traverse<true>(
+                h, ct,
+                [&](uint32_t g) {
+                    // warm[] has no boundary tail; static entries do not use it
+                    if (WARM) return Rec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : i)};
+                    return Rec{gat(PK, g), 0.0f};
+                },
+                consume);
+        else
+            nb_traverse<false>(
+                h, ct,
+                [&](uint32_t slot) {
+                    if (WARM) return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&warm_s[slot])};
+                    return Rec{lds_read_f4(&rec[slot]), 0.0f};
+                },
+                consume);
         float2 o;
         if (INV_DT) {
             o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
@@ -1583,12 +1689,18 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
                                                        uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const NbHead h = nb_head(nb, i, soff);
+    const NbHead h = nb_head(nb, i);
+    const NbStage S = nb_stage_of(nb, i >> 8, n);
     const uint32_t s = start[i];
     for (uint32_t k = 0; k < h.ct; ++k) {
-        const bool w32 = h.wide || k >= STAGE_ROWS;
-        const uint32_t raw = w32 ? *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u)) : *(const uint16_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 2u));
-        out[s + k] = raw + (w32 ? 0u : (k < h.cd ? h.base_d : h.base_s - soff));
+        uint32_t g;
+        if (h.wide) {
+            g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
+        } else {
+            const uint32_t slot = *(const uint16_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 2u));
+            g = slot < LIST_WIN ? S.lw0 + slot : S.rtab[slot - LIST_WIN];
+        }
+        out[s + k] = g < soff ? g : g - soff;
     }
 }
 __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos, uint32_t n, Consts K, uint32_t* __restrict__ key) {
@@ -1615,17 +1727,20 @@ __global__ __launch_bounds__(256) void k_view_pack(const float4* __restrict__ PV
 // publish the sticky flags / neighbour-entry count outside a solver step (sphx_update_neighborhood)
 __global__ __launch_bounds__(64) void k_publish(DevScalars* scal, Mailbox* mb, uint32_t seq) {  // one wavefront: stripes in parallel
     static_assert(STRIPES <= 64, "one lane per stripe");
-    unsigned long long nb = 0, ow = 0;
+    unsigned long long nb = 0, ow = 0, rm = 0;
     if (threadIdx.x < STRIPES) {
         nb = scal->stripe[threadIdx.x].nb_entries;
         ow = scal->stripe[threadIdx.x].owned;
+        rm = scal->stripe[threadIdx.x].rem_entries;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         nb += __shfl_down(nb, d, 64);
         ow += __shfl_down(ow, d, 64);
+        rm += __shfl_down(rm, d, 64);
     }
     if (threadIdx.x == 0) {
+        mb->rem_entries = rm;
         mb->nb_entries = nb;
         mb->owned_cum = ow;
         mb->sort_total = scal->sort_total;
