@@ -27,7 +27,8 @@
 //   cgmath 0.18  Vector2/Point2 ops: component-wise, magnitude2 = x*x + y*y, dot = x*x'+y*y'.
 //   rayon 1.5    par_sort_unstable_by_key: tie order is schedule dependent -> restated as a
 //                STABLE sort by (cidx, previous index); par_iter().sum::<f32>() tree shape is
-//                schedule dependent -> restated as an f64-accumulated sum rounded to f32.
+//                schedule dependent -> restated order-independently: terms rounded to multiples of 2^-24, added as
+//                integers, the total rounded to f32 once (sum_fixed_f64).
 //   std::time::Duration::{from_secs_f32 (round-to-nearest-even ns, Rust >= 1.63),
 //                as_secs_f32, Mul<u32>, Ord}.
 //   f32::powi    -> compiler-rt __powisf2 square-and-multiply.
@@ -668,16 +669,34 @@ struct StepStats {
     uint64_t neighbor_entries;
 };
 
-// rayon par_iter().sum::<f32>() restated as f64 accumulation rounded to f32 (see header).
-static Real sum_real(const std::vector<Real>& v) {
-    double s = 0.0;
-    const long n = (long)v.size();
+// rayon par_iter().sum::<f32>() has no defined order (the split tree is schedule dependent).  Restated ORDER-INDEPENDENTLY: every
+// term is rounded to a multiple of 2^-24 (round to nearest even; density errors are differences of floats >= rho0 = 100, i.e.
+// multiples of 2^-17: exact) and the integers are added exactly; the total goes back to f64 and is rounded to f32 once (see header).
+// Terms that are not finite or >= 2^30 make the sum NaN (the reference asserts a finite average, dfsph.rs:223 / :378).
+static double sum_fixed_f64(const Real* v, long n, const unsigned char* mask) {
+    unsigned long long hi = 0, lo = 0;  // the device keeps the sum as two 64-bit counters (high and low 32 bits of the per-block sums)
+    int bad = 0;
 #ifdef ORC_OMP
-#pragma omp parallel for schedule(static) reduction(+ : s)
+#pragma omp parallel for schedule(static) reduction(+ : hi, lo) reduction(| : bad)
 #endif
-    for (long i = 0; i < n; ++i) s += (double)v[i];
-    return (Real)s;
+    for (long b0 = 0; b0 < n; b0 += 256) {  // per 256-particle block, like the device (integer addition: any grouping gives the same total)
+        unsigned long long t = 0;
+        for (long i = b0; i < std::min(n, b0 + 256); ++i) {
+            if (mask && !mask[i]) continue;
+            const float e = v[i];
+            if (!(e < 1073741824.0f)) {
+                bad |= 1;
+                continue;
+            }
+            t += (unsigned long long)std::llrint((double)e * 16777216.0);
+        }
+        hi += t >> 32;
+        lo += t & 0xffffffffull;
+    }
+    if (bad) return std::nan("");
+    return ((double)hi * 4294967296.0 + (double)lo) * (1.0 / 16777216.0);
 }
+static Real sum_real(const std::vector<Real>& v) { return (Real)sum_fixed_f64(v.data(), (long)v.size(), nullptr); }
 
 struct DFSPHSolver {  // dfsph.rs:16-41
     XSPH viscosity_model;
@@ -1408,10 +1427,9 @@ double orc_sub_iteration(OrcSim* s, int divergence, float dt, int first) {  // d
     else
         s->dfsph.compute_density_error(dt, w, w.velocities, err);
     s->dfsph.correct_velocity(!divergence, dt, w, w.velocities, err, warm);
-    double sum = 0.0;
-    for (size_t i = 0; i < err.size(); ++i)
-        if (tile_owns(s, t, w.positions[i])) sum += (double)err[i];
-    return sum;
+    std::vector<unsigned char> owned(err.size());
+    for (size_t i = 0; i < err.size(); ++i) owned[i] = tile_owns(s, t, w.positions[i]) ? 1 : 0;
+    return sum_fixed_f64(err.data(), (long)err.size(), owned.data());
 }
 void orc_sub_advect(OrcSim* s, float dt) {  // dfsph.rs:499-510
     World& w = s->world;

@@ -41,14 +41,13 @@ constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions 
 constexpr uint32_t LIST_HALO = SPHX_LIST_HALO;
 constexpr uint32_t LIST_WIN = 256 + 2 * LIST_HALO;
 constexpr uint32_t REMOTE_CAP = 512;
-constexpr uint32_t RC_WIDE = 0xFFFFFFFFu;  // rcount marker: this workgroup's lists hold 32-bit global record indices (no staging)
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)
 constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered block on the fringe of the fluid (offsets stay < 2^31)
 constexpr uint32_t DIR_STATIC = 1u;  // dynamic directory only: the boundary's directory covers this block too (offsets are multiples of 4096)
 constexpr uint32_t DIR_FLAGS = DIR_FRINGE | DIR_STATIC;
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u, DF_NONFINITE = 128u };
 constexpr uint32_t LOOP_HIST = 512;  // residual sums of the latest solver loop kept in the mailbox (ring; the reference caps a loop at 200 / 400 (+1) iterations)
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.
@@ -77,12 +76,11 @@ struct Consts {
     uint32_t remote_cap;
 };
 
-// wave-sliced ELL neighbour lists: entry k of particle i; counts[i] = format<<31 | count_total<<16 | count_dynamic;
-// rcount[i >> 8] = number of entries of the workgroup's out-of-window table remote[(i >> 8) * REMOTE_CAP ..], or RC_WIDE
+// wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 | entries of the
+// workgroup's out-of-window table remote[(i >> 8) * REMOTE_CAP ..] << 14 | wide << 31
 struct NbView {
     const uint32_t* list;
     const uint32_t* counts;
-    const uint32_t* rcount;
     const uint32_t* remote;
 };
 
@@ -101,8 +99,14 @@ struct alignas(128) Stripe {
     unsigned long long nb_entries;  // partial sum of count_total over ALL builds so far (stats only; the host takes differences)
     unsigned long long owned;       // partial count of owned particles over ALL tile re-grids so far (host takes differences)
     unsigned long long rem_entries; // partial sum of out-of-window list entries over ALL builds so far (stats only)
-    uint32_t ticket;                // first-level arrival counter of the last-block reductions
-    uint32_t pad[25];
+    // Reductions without a tail: a workgroup adds its share with fire-and-forget integer atomics and is gone; the
+    // NEXT kernel on the stream reads the 32 stripes.  res_hi/res_lo: residual sums in 2^-24 fixed point, cumulative over ALL
+    // iterations so far (never reset: readers take differences); vmax[]: max |v + a dt|^2 bits, a ring of 4 (the reader of slot v
+    // clears slot v + 2).
+    unsigned long long res_hi, res_lo;
+    uint32_t vmax[4];
+    uint32_t ticket;                // first-level arrival counter of the last-block reduction (two-pass scan only)
+    uint32_t pad[17];
 };
 struct DevScalars {
     uint32_t flags;        // DF_*
@@ -110,7 +114,9 @@ struct DevScalars {
     uint32_t sort_total;   // number of particles that received a cell in the latest histogram scan (tile mode: new local count)
     float dt;              // time step the device derived from vmax with the host's timer law (sphx_step_begin_law)
     uint32_t loop_done;    // solver loop run by the device (LoopArgs): 0 while it iterates, else the iteration that met the residual test
-    uint32_t pad[27];
+    uint32_t pad0;
+    unsigned long long snap_hi[2], snap_lo[2];  // cumulative residual sums after the iteration with reduction sequence number r at [r & 1]
+    uint32_t pad[18];
     Stripe stripe[STRIPES];
 };
 
@@ -137,6 +143,20 @@ struct Mailbox {
 // holds the residual sum, applies dfsph.rs:221-236 / :376-391 to it and records the outcome in DevScalars::loop_done; iterations
 // queued behind the terminating one return at once, and the density correction of the terminating iteration (it knows it is the
 // last) does the re-grid's advection + cell count.  The host verifies every decision from loop_hist afterwards.
+// Who reads a reduction: the kernel queued behind the one that produced it.  Every workgroup of the reader derives the same value
+// from the stripes; its workgroup 0 publishes to the mailbox.
+struct ResArgs {  // reader of the residual sum of a compute_error launch (the correction of the same iteration)
+    uint32_t enabled;
+    uint32_t rseq;  // reduction sequence number of this iteration (the context counts them; consecutive)
+    Mailbox* mb;
+    uint32_t seq;   // mailbox sequence number the residual is published under
+};
+struct VmaxArgs {  // reader of max |v + a dt|^2 (the velocity prediction, or k_publish_vmax)
+    uint32_t enabled;
+    uint32_t vslot;  // ring slot the producer used
+    Mailbox* mb;
+    uint32_t seq;
+};
 struct LoopArgs {
     uint32_t enabled;    // 0: host-driven loop (tile mode: the residual needs an all-reduce over the ranks)
     uint32_t iter;       // 1-based index of this iteration
@@ -146,6 +166,7 @@ struct LoopArgs {
     uint32_t n_total;    // particles the average runs over
     float tol;           // dfsph.rs:49 / :53
     float rho0;
+    float dt;            // the step (host value; kernels given dt_dev use the device's)
 };
 
 // TimeManager::update_simulation_step (timemanager.rs:252-279) as the device applies it to its own vmax
@@ -222,15 +243,16 @@ struct sphx_ctx {
     std::vector<float> h_boundary;  // host copy of the boundary (caller order): the static directory is built on the host
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
-    uint32_t* nb_counts = nullptr;  // format << 31 | count_total << 16 | count_dynamic
-    uint32_t* nb_rcount = nullptr;  // per 256-particle workgroup: entries in its out-of-window table, or RC_WIDE
-    uint32_t* nb_remote = nullptr;  // per workgroup REMOTE_CAP global record indices
+    uint32_t* nb_counts = nullptr;  // NeighborRange + list format of the particle's workgroup (nb_count_word)
+    uint32_t* nb_remote = nullptr;  // per 256-particle workgroup REMOTE_CAP global record indices
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
     uint32_t pre_gen = 0;     // ... and their loop generation
     uint32_t pre_queued = 0;  // density iterations sphx_step_begin_law has put on the stream (device-run loop)
     uint32_t loop_gen = 0;    // generation counter of the device-run solver loops
+    uint32_t res_seq = 0;     // reduction sequence number of the solver iterations (ResArgs)
+    uint32_t vmax_seq = 0;    // ... and of the max-velocity reductions (VmaxArgs::vslot = vmax_seq & 3)
     int host_loop = 0;        // SPHX_HOST_LOOP=1: the host judges every residual (round-1 behaviour; A/B runs)
     std::string prof_filter;  // sphx_profile_filter: only launches with this label are timed, every prof_every-th of them
     uint32_t prof_every = 1, prof_counter = 0;
@@ -244,7 +266,7 @@ struct sphx_ctx {
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;
-    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_rcount, nb_remote}; }
+    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_remote}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;
@@ -255,7 +277,6 @@ struct sphx_ctx {
     uint32_t count_n = 0;
     int no_fused_count = 0;      // SPHX_NO_FUSED_COUNT=1 (A/B runs)
     int scan_two_pass = 0;  // SPHX_SCAN_TWO_PASS=1: the two-launch scan (A/B runs)
-    double* red_partials = nullptr;  // one slot per workgroup (also reinterpreted as u32 for the max reduction)
     // scalars
     sphx::DevScalars* d_scal = nullptr;
     sphx::Mailbox* mbox = nullptr;      // pinned host memory

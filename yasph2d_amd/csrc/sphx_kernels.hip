@@ -114,6 +114,11 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
 }
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
 
+// NeighborRange (neighborhood_search.rs:269-273) of one particle + the list format of its workgroup in one word:
+// count_dynamic (7 bits) | count_total << 7 | entries of the workgroup's out-of-window table << 14 | wide << 31
+__device__ __forceinline__ uint32_t nb_count_word(uint32_t cd, uint32_t ct, uint32_t r, bool wide) {
+    return cd | (ct << 7) | (r << 14) | ((wide ? 1u : 0u) << 31);
+}
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
@@ -899,7 +904,7 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 template <bool FUSE>
 __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
                                                          GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ rcount, uint32_t* __restrict__ remote, float* __restrict__ density,
+                                                         uint32_t* __restrict__ remote, float* __restrict__ density,
                                                          float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
@@ -1004,12 +1009,39 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
     }
+    if (FUSE && i < n) {
+        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order
+        float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
+        float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
+        for (uint32_t k = 0; k < ct; ++k) {
+            uint32_t j = lds_read_u32(&tile[w][min(k, STAGE_ROWS - 1u)][lane]);
+            if (k >= STAGE_ROWS) j = list[ell_index(i, k)];
+            const uint32_t wj = j - w0;  // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
+            float2 rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
+            if (wj >= wlen) rj = gat(posA, j);
+            const float dx = rj.x - pi.x, dy = rj.y - pi.y;
+            const float r = sqrt_dist(dx * dx + dy * dy);
+            const float q = fminf(r * K.w_hinv, 1.0f);
+            const float omq = 1.0f - q;
+            const float omq_sq = omq * omq;
+            rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
+            const float sg = K.w_ngrad * omq * omq * omq;
+            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+            gsx += gx;
+            gsy += gy;
+            gss += gx * gx + gy * gy;
+        }
+        density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
+        alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
+    }
     // ---- list format of this workgroup (NbHead) ------------------------------------------------------------------------------
     // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
     // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
     // away in Morton order, or a boundary particle) gets the next free line r of this workgroup's out-of-window table and is stored
     // as LIST_WIN + r.  Lines are handed out in a fixed order (wave, row, lane).  A workgroup with more than remote_cap such
-    // entries keeps 32-bit global slots (RC_WIDE; its traversals gather from global memory).
+    // entries keeps 32-bit global slots (wide; its traversals gather from global memory).
+    // 16-bit layout of a wave's slice: entries 4q .. 4q+3 of a lane are one 8-byte word at q * 512 + lane * 8, so a traversal
+    // fetches the first twelve entries of its particle with three coalesced loads that depend on nothing.
     __shared__ uint32_t wtot[4];
     const uint32_t lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     const uint32_t lwlen = min(b0 + 256u + LIST_HALO, n) - lw0;
@@ -1036,15 +1068,15 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     uint32_t run = (w > 0 ? wtot[0] : 0u) + (w > 1 ? wtot[1] : 0u) + (w > 2 ? wtot[2] : 0u);
     const bool wide = rtot > K.remote_cap || K.remote_cap == 0u;
     uint32_t* const rtab = remote + (size_t)xcd_bid() * REMOTE_CAP;
-    if (i < n) counts[i] = ((wide ? 1u : 0u) << 31) | (ct << 16) | cd;
-    if (threadIdx.x == 0) rcount[xcd_bid()] = wide ? RC_WIDE : rtot;
-    // pass B: rows out, one coalesced row per store (lanes past their own count write don't-care values)
+    if (i < n) counts[i] = nb_count_word(cd, ct, wide ? 0u : rtot, wide);
+    // pass B: rows out, coalesced (lanes past their own count write don't-care values)
     if (wide) {
         const size_t row0 = (size_t)(i >> 6) * 64;
         for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = lds_read_u32(&tile[w][k][lane]);
     } else {
-        uint16_t* const lp16 = (uint16_t*)(list + (size_t)(i >> 6) * 4096) + lane;
+        char* const slice = (char*)(list + (size_t)(i >> 6) * 4096);
         const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t packed[2] = {0u, 0u};
         for (uint32_t k = 0; k < m; ++k) {
             const uint32_t g = lds_read_u32(&tile[w][k][lane]);
             const bool rem = k < ct && g - lw0 >= lwlen;
@@ -1052,47 +1084,29 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
             const uint32_t r = run + (uint32_t)__popcll(mask & below);
             run += (uint32_t)__popcll(mask);
             if (rem) rtab[r] = g;
-            lp16[k * 64] = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
+            const uint32_t slot = (rem ? LIST_WIN + r : g - lw0) & 0xffffu;
+            const uint32_t q = k & 3u;
+            if (q == 0u) packed[0] = slot;
+            if (q == 1u) packed[0] |= slot << 16;
+            if (q == 2u) packed[1] = slot;
+            if (q == 3u) packed[1] |= slot << 16;
+            if (q == 3u || k + 1u == m) *(uint2*)(slice + (k >> 2) * 512u + lane * 8u) = make_uint2(packed[0], packed[1]);
         }
         if (spill) {
-            // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their RC_WIDE address); the
-            // 16-bit row k lies below every 32-bit row >= k, so rewriting in ascending k never overwrites an entry still to be read
+            // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address, byte
+            // 256 k + 4 lane); their 16-bit home, byte 128 (k & ~3) + 8 lane + 2 (k & 3), lies below every 32-bit row >= k, so
+            // rewriting in ascending k never overwrites an entry still to be read
             uint32_t r = run + spill_before;
             for (uint32_t k = STAGE_ROWS; k < ct; ++k) {
                 const uint32_t g = list[ell_index(i, k)];
                 const bool rem = g - lw0 >= lwlen;
                 if (rem) rtab[r] = g;
-                lp16[k * 64] = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
+                *(uint16_t*)(slice + (k >> 2) * 512u + lane * 8u + (k & 3u) * 2u) = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
                 r += rem ? 1u : 0u;
             }
         }
     }
 
-    if (FUSE && i < n) {
-        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order
-        float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
-        float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-        for (uint32_t k = 0; k < ct; ++k) {
-            uint32_t j = lds_read_u32(&tile[w][min(k, STAGE_ROWS - 1u)][lane]);
-            if (k >= STAGE_ROWS) j = list[ell_index(i, k)];
-            const uint32_t wj = j - w0;  // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
-            float2 rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
-            if (wj >= wlen) rj = gat(posA, j);
-            const float dx = rj.x - pi.x, dy = rj.y - pi.y;
-            const float r = sqrt_dist(dx * dx + dy * dy);
-            const float q = fminf(r * K.w_hinv, 1.0f);
-            const float omq = 1.0f - q;
-            const float omq_sq = omq * omq;
-            rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
-            const float sg = K.w_ngrad * omq * omq * omq;
-            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-            gsx += gx;
-            gsy += gy;
-            gss += gx * gx + gy * gy;
-        }
-        density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
-        alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
-    }
     // total number of list entries and of out-of-window entries (stats only): block reduce, striped atomics per workgroup
     unsigned long long tot = ct;
 #pragma unroll
@@ -1124,6 +1138,9 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
 #define NB_BATCH 4
 #endif
 constexpr uint32_t STAGE_SLOTS = LIST_WIN + REMOTE_CAP;
+static_assert((STAGE_SLOTS & (STAGE_SLOTS - 1)) == 0, "don't-care list entries are masked into the staging area");
+static_assert(LIST_WIN % 256 == 0 && REMOTE_CAP % 256 == 0 && STAGE_ROWS % 4 == 0, "staging loops / packed groups");
+constexpr uint32_t NB_G0 = 3;  // packed 4-entry groups every traversal loads up front (12 entries; the rest on demand)
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u32x4_t lds_cu128;
@@ -1133,84 +1150,109 @@ __device__ __forceinline__ float4 lds_read_f4(const float4* p) {
 }
 __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
-// Geometry of a workgroup's staging area; identical in the build and in every traversal kernel.
-struct NbStage {
+// Everything a lane needs to walk its list, fetched with loads that depend on nothing but the lane's index: the kernels are
+// bound by the LENGTH of their dependent load chain (count -> index -> record -> next index ...: seven round trips in the
+// round-1 kernels), not by bytes, so count word, the first twelve entries, the window records and the out-of-window table are all
+// requested before anything is waited for.
+struct NbHead {
+    uint32_t cd, ct;      // NeighborRange: dynamic / total neighbours
+    uint32_t R;           // entries of the workgroup's out-of-window table (0 when wide)
+    bool wide;            // lists hold 32-bit global slots, nothing is staged (workgroup-uniform)
+    uint2 e[NB_G0];       // entries 0..11, four 16-bit staging slots per word pair (narrow format)
+    const char* rows;     // this wave's 16 KiB slice of the list buffer
+    uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
-    uint32_t R;           // entries of the out-of-window table (0 when wide)
-    bool wide;            // RC_WIDE: lists hold global slots, nothing is staged
     const uint32_t* rtab;
 };
-__device__ __forceinline__ NbStage nb_stage_of(const NbView& nb, uint32_t blk, uint32_t n) {
-    NbStage S;
-    const uint32_t b0 = blk * 256u;
-    S.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
-    S.lwlen = b0 < n ? min(b0 + 256u + LIST_HALO, n) - S.lw0 : 0u;
-    const uint32_t rc = b0 < n ? nb.rcount[blk] : 0u;  // workgroups past the last particle have no lists
-    S.wide = rc == RC_WIDE;
-    S.R = S.wide ? 0u : min(rc, REMOTE_CAP);
-    if (S.wide) S.lwlen = 0u;
-    S.rtab = nb.remote + (size_t)blk * REMOTE_CAP;
-    return S;
-}
-// rec[0 .. lwlen) = src[lw0 ..]; rec[LIST_WIN + r] = src[rtab[r]] (zero for table entries >= limit: arrays without a boundary tail).
-// Called by all threads of the workgroup; the caller places the barrier.
-template <class T>
-__device__ __forceinline__ void nb_stage_load(T* rec, const T* __restrict__ src, const NbStage& S, uint32_t limit) {
-    for (uint32_t t = threadIdx.x; t < S.lwlen; t += 256) rec[t] = src[S.lw0 + t];
-    for (uint32_t t = threadIdx.x; t < S.R; t += 256) {
-        const uint32_t g = S.rtab[t];
-        T v{};
-        if (g < limit) v = gat(src, g);
-        rec[LIST_WIN + t] = v;
-    }
-}
-
-struct NbHead {
-    uint32_t cd, ct;
-    bool wide;
-    const char* rows;  // this wave's 16 KiB slice of the list buffer (wave-uniform: scalar base + 32-bit lane offsets)
-    uint32_t lane;
-};
-__device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t i) {
+__device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
     NbHead h;
-    const uint32_t c = nb.counts[i];
-    h.cd = c & 0xffffu;
-    h.ct = (c >> 16) & 0x7fffu;
+    const uint32_t b0 = blk * 256u;
+    const bool active = b0 < n;  // the grid is rounded up: workgroups past the last particle have no lists
+    // lanes past n (last workgroup) read the format of their workgroup from its first particle
+    const uint32_t c = active ? nb.counts[i < n ? i : b0] : 0u;
+    h.cd = i < n ? c & 0x7fu : 0u;
+    h.ct = i < n ? (c >> 7) & 0x7fu : 0u;
     h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
-    h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
+    h.R = h.wide ? 0u : min((uint32_t)__builtin_amdgcn_readfirstlane((c >> 14) & 0x3ffu), REMOTE_CAP);
     h.lane = i & 63u;
+    h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
+#pragma unroll
+    for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
+    h.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
+    h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
+    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP;
     return h;
 }
-// Entries k0 .. k0+NB_BATCH-1 (k0 < lim): staging slots (16-bit rows) or global slots (32-bit rows, WIDE).  Entries past the end
-// repeat entry lim-1, so every load of a batch is unconditional — no branch per entry; the callers discard the padded terms with a
-// select.
-template <bool WIDE>
-__device__ __forceinline__ void nb_fetch(const NbHead& h, uint32_t k0, uint32_t lim, uint32_t (&j)[NB_BATCH]) {
-    const uint32_t last = lim - 1u;
+// Fill the staging area: load(g) -> record of slot g of the [N|B] arrays (any type), store(slot, record) writes it to LDS.  Every
+// load of a thread is issued before the first store (the loads of the out-of-window lines wait for nothing but the table lines
+// and the count word, which were requested first).  Called by all 256 threads; the caller places the barrier.
+template <class L, class S>
+__device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
+    if (h.wide || h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
+    constexpr uint32_t NW = LIST_WIN / 256, NR = REMOTE_CAP / 256;
+    uint32_t g[NR];
 #pragma unroll
-    for (int u = 0; u < NB_BATCH; ++u) {
-        const uint32_t kk = min(k0 + u, last);
-        if (WIDE)
-            j[u] = *(const uint32_t*)(h.rows + (uint32_t)((kk * 64u + h.lane) * 4u));
-        else
-            j[u] = *(const uint16_t*)(h.rows + (uint32_t)((kk * 64u + h.lane) * 2u));
+    for (uint32_t u = 0; u < NR; ++u) g[u] = h.rtab[threadIdx.x + u * 256u];  // lines past R: don't-care
+    decltype(load(0u)) wrec[NW], rrec[NR];
+#pragma unroll
+    for (uint32_t u = 0; u < NW; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads (lwlen >= 1 here)
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NR; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        rrec[u] = load(t < h.R ? g[u] : h.lw0);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NW; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        if (t < h.lwlen) store(t, wrec[u]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NR; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        if (t < h.R) store(LIST_WIN + t, rrec[u]);
     }
 }
-// Software-pipelined traversal of entries 0..lim-1 in list order: the index loads of batch b+1 are issued right after the record
-// reads of batch b, before those are consumed.
-//   gather(slot) -> record (any type);   consume(record, k) must ignore k >= lim (padded entries repeat entry lim-1).
-template <bool WIDE, class G, class C>
-__device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, G&& gather, C&& consume) {
-    if (lim == 0) return;
-    uint32_t jn[NB_BATCH];
-    nb_fetch<WIDE>(h, 0, lim, jn);
-    for (uint32_t k0 = 0; k0 < lim; k0 += NB_BATCH) {
-        decltype(gather(0u)) r[NB_BATCH];
+// Traversal of entries 0..lim-1 in list order.  gather(x) -> record: x = staging slot (narrow) or global slot (wide);
+// consume(record, k) must ignore k >= lim.
+template <class GL, class GG, class C>
+__device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& gather_lds, GG&& gather_global, C&& consume) {
+    if (!h.wide) {
+        auto group = [&](const uint2 e, uint32_t q) {
+            const uint32_t s4[4] = {e.x & 0xffffu, e.x >> 16, e.y & 0xffffu, e.y >> 16};
+            decltype(gather_lds(0u)) r[4];
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) r[u] = gather(jn[u]);
-        nb_fetch<WIDE>(h, k0 + NB_BATCH, lim, jn);  // clamped to the last entry when the list ends here
+            for (int u = 0; u < 4; ++u) r[u] = gather_lds(s4[u] & (STAGE_SLOTS - 1u));  // entries >= lim hold don't-care values
 #pragma unroll
-        for (int u = 0; u < NB_BATCH; ++u) consume(r[u], k0 + (uint32_t)u);
+            for (int u = 0; u < 4; ++u) consume(r[u], 4u * q + (uint32_t)u);
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < NB_G0; ++q) {
+            if (!__any(lim > 4u * q)) return;
+            group(h.e[q], q);
+        }
+        for (uint32_t q = NB_G0; __any(lim > 4u * q); ++q) group(*(const uint2*)(h.rows + q * 512u + h.lane * 8u), q);
+    } else {
+        // round-1 path: 32-bit rows, records gathered from global memory, batches of NB_BATCH with the index loads of the next
+        // batch issued behind the gathers of the current one
+        if (lim == 0) return;
+        const uint32_t last = lim - 1u;
+        auto fetch = [&](uint32_t k0, uint32_t (&j)[NB_BATCH]) {
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) j[u] = *(const uint32_t*)(h.rows + (uint32_t)((min(k0 + u, last) * 64u + h.lane) * 4u));
+        };
+        uint32_t jn[NB_BATCH];
+        fetch(0, jn);
+        for (uint32_t k0 = 0; k0 < lim; k0 += NB_BATCH) {
+            decltype(gather_global(0u)) r[NB_BATCH];
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) r[u] = gather_global(jn[u]);
+            fetch(k0 + NB_BATCH, jn);  // clamped to the last entry when the list ends here
+#pragma unroll
+            for (int u = 0; u < NB_BATCH; ++u) consume(r[u], k0 + (uint32_t)u);
+        }
     }
 }
 
@@ -1222,12 +1264,11 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     __shared__ float2 rec[STAGE_SLOTS];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbStage S = nb_stage_of(nb, blk, n);
-    nb_stage_load(rec, posA, S, 0xFFFFFFFFu);
+    const NbHead h = nb_head(nb, blk, i, n);
+    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec[slot] = r; });
     __syncthreads();
     if (i >= n) return;
-    const NbHead h = nb_head(nb, i);
-    const float2 ri = S.wide ? posA[i] : lds_read_f2(&rec[i - S.lw0]);
+    const float2 ri = h.wide ? posA[i] : lds_read_f2(&rec[i - h.lw0]);
     const uint32_t ct = h.ct;
     float rho = 0.0f;
     if (DENSITY) {
@@ -1260,10 +1301,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
             gss = live ? ts : gss;
         }
     };
-    if (S.wide)
-        nb_traverse<true>(h, ct, [&](uint32_t g) { return gat(posA, g); }, consume);
-    else
-        nb_traverse<false>(h, ct, [&](uint32_t slot) { return lds_read_f2(&rec[slot]); }, consume);
+    nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f2(&rec[slot]); }, [&](uint32_t g) { return gat(posA, g); }, consume);
     if (DENSITY) density[i] = fmaxf(rho, K.rho0);                                  // fluidparticleworld.rs:229
     if (ALPHA) alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);     // dfsph.rs:94
 }
@@ -1304,55 +1342,116 @@ __device__ __forceinline__ unsigned long long timer_law_step_ns(const TimerLaw& 
     return max(law.min_ns, min(upper, cfl_ns));
 }
 
-// max over all workgroups of a per-lane non-negative float, exact (non-negative floats order like their bit patterns); the last
-// workgroup to arrive publishes it to the mailbox — and, given a timer law, the dt the host's TimeManager will derive from it
-__device__ __forceinline__ void reduce_publish_vmax(float vsq, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
-                                                    Mailbox* __restrict__ mb, uint32_t seq, const TimerLaw& law) {
+// ---- reductions without a tail ------------------------------------------------------------------------------------------------
+// A last-block reduction (partial store, drain, returning ticket atomic, barrier) kept every workgroup alive for two more memory
+// round trips: a third of the run time of compute_error / nonpressure (profiles/r02_*).  Here a workgroup adds its share with
+// no-return integer atomics — order-independent, so the result is deterministic — and ends; the kernel queued behind reads the 32
+// stripes (every workgroup the same value) and its workgroup 0 publishes to the pinned mailbox.
+
+// max |v + a dt|^2: non-negative floats order like their bit patterns (NaN patterns sort above +inf: a NaN is not lost)
+__device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t m = block_max_u32(__float_as_uint(vsq));
-    __shared__ uint32_t last_s;
+    if (threadIdx.x == 0 && m) atomicMax(&scal->stripe[blockIdx.x % STRIPES].vmax[vslot & 3u], m);
+}
+// called by a whole wavefront; every lane returns the maximum
+__device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__ scal, uint32_t vslot) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t b = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].vmax[vslot & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+    return b;
+}
+// The reader's workgroup 0 (its first wavefront) clears the slot that comes into use two reductions later and publishes.
+__device__ __forceinline__ void vmax_publish(DevScalars* __restrict__ scal, const VmaxArgs& va, uint32_t bits, const TimerLaw& law, unsigned long long ns,
+                                             float dt_new) {
+    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->stripe[threadIdx.x].vmax[(va.vslot + 2u) & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&partials[xcd_bid()], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = arrive_is_last(scal) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last_s) {
-        uint32_t b = 0;
-        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) b = max(b, __hip_atomic_load(&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        b = block_max_u32(b);
-        if (threadIdx.x == 0) {
-            mb->vmax_sq_bits = b;
-            if (law.enabled) {
-                // the step the host's TimeManager will arrive at (dfsph.rs:478-480): the kernels queued behind this one read it
-                // from scal->dt instead of waiting for the host round trip
-                const unsigned long long ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
-                const float dt_new = duration_as_secs_f32(ns);
-                __hip_atomic_store((uint32_t*)&scal->dt, __float_as_uint(dt_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mb->dt_ns = ns;
-                mb->dt_bits = __float_as_uint(dt_new);
-            }
+        va.mb->vmax_sq_bits = bits;
+        if (law.enabled) {
+            // the step the host's TimeManager will arrive at (dfsph.rs:478-480): the kernels queued behind read it from scal->dt
+            __hip_atomic_store((uint32_t*)&scal->dt, __float_as_uint(dt_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            va.mb->dt_ns = ns;
+            va.mb->dt_bits = __float_as_uint(dt_new);
         }
-        publish_common(scal, mb, seq);
     }
+    publish_common(scal, va.mb, va.seq);
+}
+
+// Residual sums (dfsph.rs:221 / :377; rayon's par_iter().sum::<f32>() has no defined order): every term is rounded to a multiple
+// of 2^-24 (round to nearest even; density errors are multiples of 2^-17 anyway: exact) and the integers are added exactly —
+// the sum does not depend on any order.  Terms that are not finite or >= 2^30 raise DF_NONFINITE (the reference asserts a finite
+// average, dfsph.rs:223 / :378).
+__device__ __forceinline__ unsigned long long residual_fixed(float e, bool& bad) {
+    bad = !(e < 1073741824.0f);
+    const float t = __builtin_rintf((bad ? 0.0f : e) * 16777216.0f);  // exact scaling; integral from here on (>= 2^23: already integral)
+    const uint32_t bits = __float_as_uint(t);
+    const uint32_t m = (bits & 0x7fffffu) | 0x800000u;
+    const int sh = (int)((bits >> 23) & 0xffu) - 150;
+    unsigned long long f = sh >= 0 ? (unsigned long long)m << (sh & 63) : (unsigned long long)(m >> min(-sh, 31));
+    return (bits & 0x7f800000u) ? f : 0ull;  // zero (and -0)
+}
+__device__ __forceinline__ void block_residual_add(float e, DevScalars* __restrict__ scal) {
+    bool bad;
+    unsigned long long f = residual_fixed(e, bad);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) f += __shfl_down(f, d, 64);
+    __shared__ unsigned long long ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = f;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&scal->flags, DF_NONFINITE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];  // < 2^62
+        Stripe* st = &scal->stripe[blockIdx.x % STRIPES];
+        if (t >> 32) atomicAdd(&st->res_hi, t >> 32);
+        if (t & 0xffffffffull) atomicAdd(&st->res_lo, t & 0xffffffffull);
+    }
+}
+// called by a whole wavefront; every lane returns the cumulative sums
+__device__ __forceinline__ void wave_residual_total(const DevScalars* __restrict__ scal, unsigned long long& hi, unsigned long long& lo) {
+    const uint32_t lane = threadIdx.x & 63u;
+    hi = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    lo = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        hi += __shfl_xor(hi, d, 64);
+        lo += __shfl_xor(lo, d, 64);
+    }
+}
+// cumulative sums now and after the previous iteration -> the residual sum of this iteration as the f64 the host works with
+__device__ __forceinline__ double residual_sum_f64(unsigned long long hi, unsigned long long lo, unsigned long long hi0, unsigned long long lo0) {
+    return ((double)(hi - hi0) * 4294967296.0 + (double)(lo - lo0)) * (1.0 / 16777216.0);
+}
+
+// Reader of the max-velocity reduction when no kernel of the step is queued behind it (plain sphx_step_begin, WCSPH, tiles)
+__global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs va) {
+    const uint32_t b = wave_vmax_get(scal, va.vslot);
+    vmax_publish(scal, va, b, TimerLaw{}, 0ull, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
-                                                      float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials, DevScalars* __restrict__ scal,
-                                                      Mailbox* __restrict__ mb, uint32_t seq, TimerLaw law) {
+                                                      float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float rho_s[STAGE_SLOTS];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbStage S = nb_stage_of(nb, blk, n);
-    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
-    nb_stage_load(rho_s, density, S, soff);  // density[] has no boundary tail (XSPH runs over dynamic neighbours only, dfsph.rs:456)
+    const NbHead h = nb_head(nb, blk, i, n);
+    struct StageRec {
+        float4 pv;
+        float rho;
+    };
+    nb_stage(
+        h, [&](uint32_t g) { return StageRec{gat(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
+        [&](uint32_t slot, const StageRec& r) {
+            rec[slot] = r.pv;
+            rho_s[slot] = r.rho;
+        });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
-        const NbHead h = nb_head(nb, i);
+        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
@@ -1368,22 +1467,30 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
             ax = k < cd ? tx : ax;
             ay = k < cd ? ty : ay;
         };
-        if (S.wide)
-            nb_traverse<true>(h, cd, [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g)}; }, consume);
-        else
-            nb_traverse<false>(h, cd, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; }, consume);
+        nb_traverse(
+            h, cd, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
+            [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
-    reduce_publish_vmax(vsq, partials, scal, mb, seq, law);
+    block_vmax_add(vsq, scal, vslot);
 }
 
-// a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524)
-// dt_dev (all kernels that take it): the step derived on the device (TimerLaw); nullptr = use the host's argument
+// a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
+// va.enabled: this launch is queued right behind the non-pressure pass and READS its max-velocity reduction: every workgroup
+// derives the step the host's TimeManager will arrive at from it (TimerLaw), workgroup 0 publishes vmax and dt.
 __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt,
-                                                  const float* __restrict__ dt_dev) {
-    if (dt_dev) dt = *dt_dev;
+                                                  DevScalars* __restrict__ scal, VmaxArgs va, TimerLaw law) {
+    if (va.enabled) {
+        const uint32_t b = wave_vmax_get(scal, va.vslot);
+        unsigned long long ns = 0;
+        if (law.enabled) {
+            ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
+            dt = duration_as_secs_f32(ns);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 64) vmax_publish(scal, va, b, law, ns, dt);
+    }
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
     float4 pv = PV[i];
@@ -1426,21 +1533,27 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
 }
 // update_accellerations (wscsph.rs:59-118) + max |v + a*dt|^2 (wscsph.rs:158-161)
 __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
-                                          float dt, NbView nb, float2* __restrict__ accel, uint32_t* __restrict__ partials,
-                                          DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq) {
+                                          float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float rho_s[STAGE_SLOTS];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbStage S = nb_stage_of(nb, blk, n);
-    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
-    nb_stage_load(rho_s, density, S, soff);  // density[] has no boundary tail; static entries do not use it
+    const NbHead h = nb_head(nb, blk, i, n);
+    struct StageRec {
+        float4 pv;
+        float rho;
+    };
+    nb_stage(
+        h, [&](uint32_t g) { return StageRec{gat(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
+        [&](uint32_t slot, const StageRec& r) {
+            rec[slot] = r.pv;
+            rho_s[slot] = r.rho;
+        });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
+        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
         const float rhoi = density[i];
-        const NbHead h = nb_head(nb, i);
         const uint32_t cd = h.cd, ct = h.ct;
         float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
         const float pi = wcsph_pressure(K, rhoi);
@@ -1471,15 +1584,14 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
             ax = k < ct ? tx : ax;
             ay = k < ct ? ty : ay;
         };
-        if (S.wide)
-            nb_traverse<true>(h, ct, [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g < soff ? g : i)}; }, consume);
-        else
-            nb_traverse<false>(h, ct, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; }, consume);
+        nb_traverse(
+            h, ct, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
+            [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g < soff ? g : i)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;
     }
-    reduce_publish_vmax(vsq, partials, scal, mb, seq, TimerLaw{});
+    block_vmax_add(vsq, scal, vslot);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1489,23 +1601,24 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
 template <bool DIVERGENCE>
 __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
-                                                        NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero, double* __restrict__ partials,
-                                                        DevScalars* __restrict__ scal, Mailbox* __restrict__ mb, uint32_t seq,
-                                                        const float* __restrict__ dt_dev, LoopArgs la) {
+                                                        NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero,
+                                                        DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la) {
     // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
     if (la.enabled && la.iter > 1u && scal->loop_done != 0u) return;
     if (dt_dev) dt = *dt_dev;
     __shared__ float4 rec[STAGE_SLOTS];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbStage S = nb_stage_of(nb, blk, n);
-    nb_stage_load(rec, PV, S, 0xFFFFFFFFu);
+    const NbHead h = nb_head(nb, blk, i, n);
+    // this particle's scalars are requested together with everything else (one round trip, not two)
+    const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
+    const float alpha_i = i < n ? alpha[i] : 0.0f;
+    nb_stage(h, [&](uint32_t g) { return gat(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
-        const NbHead h = nb_head(nb, i);
         const uint32_t ct = h.ct;
-        const float4 pvi = S.wide ? PV[i] : lds_read_f4(&rec[i - S.lw0]);
+        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
@@ -1516,61 +1629,19 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
                 const float t = delta + (dvx * g.x + dvy * g.y);
                 delta = k < ct ? t : delta;
             };
-            if (S.wide)
-                nb_traverse<true>(h, ct, [&](uint32_t g) { return gat(PV, g); }, consume);
-            else
-                nb_traverse<false>(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, consume);
+            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, [&](uint32_t g) { return gat(PV, g); }, consume);
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
-                e = density[i] + delta * K.mass * dt;  // dfsph.rs:121
+                e = rho_i + delta * K.mass * dt;  // dfsph.rs:121
                 e = fmaxf(K.rho0, e) - K.rho0;         // dfsph.rs:124
             }
         }
-        PK[i] = make_float4(pvi.x, pvi.y, e * alpha[i], e);
+        PK[i] = make_float4(pvi.x, pvi.y, e * alpha_i, e);
         if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363, folded into the first iteration
         e_owned = tile_owns(K, pvi.x, pvi.y) ? e : 0.0f;
     }
-    const double bs = block_sum_f64((double)e_owned);
-    __shared__ uint32_t last_s;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store((unsigned long long*)&partials[xcd_bid()], (unsigned long long)__double_as_longlong(bs), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        last_s = arrive_is_last(scal) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last_s) {
-        double s = 0.0;
-        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256)
-            s += __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&partials[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        s = block_sum_f64(s);
-        if (threadIdx.x == 0) {
-            mb->err_sum = s;
-            if (la.enabled) {
-                // dfsph.rs:221-236 / :376-391 on the spot, in the host's operations (f64 sum rounded once, two f32 divisions, one product)
-                mb->loop_hist[la.iter % LOOP_HIST] = s;
-                const float sum = (float)s;
-                const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
-                bool more;
-                if (!(fabsf(avg) <= 3.402823466e38f)) {
-                    more = false;  // not finite: the reference panics (dfsph.rs:223 / :378); the host reports it from loop_hist
-                } else if (la.fixed) {
-                    more = la.iter < la.fixed;
-                } else {
-                    const float rel = DIVERGENCE ? avg : avg / la.rho0;  // dfsph.rs:222
-                    more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
-                    if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
-                }
-                __hip_atomic_store(&scal->loop_done, more ? 0u : la.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!more) {
-                    mb->loop_iters = la.iter;
-                    __threadfence_system();
-                    __hip_atomic_store((uint32_t*)&mb->loop_gen_done, la.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-        }
-        publish_common(scal, mb, seq);
-    }
+    block_residual_add(e_owned, scal);  // read by the correction queued behind this launch (ResArgs)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1582,7 +1653,7 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // advection + cell count of the re-grid that follows (k_key_count<true>) needs, so the correction does it on the spot and the
 // re-grid starts at the scan.  Whether a correction is the last one is only known afterwards (the residual decides): every density
 // correction counts, and the host clears the histogram again when another iteration follows — unless the loop is run by the device
-// (LoopArgs): then the correction knows from its own compute_error whether it is the last one, and only the last one counts.
+// (LoopArgs): then the correction derives the verdict from the residual itself and only the last one counts.
 // hist == nullptr: plain correction.
 struct CountArgs {
     GridView g;
@@ -1592,36 +1663,100 @@ struct CountArgs {
 template <bool WARM, bool INV_DT>
 __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
-                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la) {
-    // device-run loop: loop_done was settled by this iteration's compute_error (0: more follow; == iter: this is the last one)
-    const uint32_t done = la.enabled ? scal->loop_done : 0u;
-    if (done != 0u && done < la.iter) return;
-    float dt = ca.dt;
+                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra) {
+    float dt = WARM ? ca.dt : (la.enabled ? la.dt : ca.dt);
     if (dt_dev) {
         dt = *dt_dev;
         inv_dt = 1.0f / dt;
+    }
+    // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs):
+    // every workgroup derives the same sum and — in a device-run loop (LoopArgs) — the same verdict of dfsph.rs:221-236 / :376-391;
+    // workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox.
+    bool last = true;  // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
+    if (!WARM && ra.enabled) {
+        constexpr bool DIVERGENCE = !INV_DT;
+        // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
+        const uint32_t done_before = (la.enabled && la.iter > 1u) ? scal->loop_done : 0u;
+        unsigned long long hi, lo;
+        wave_residual_total(scal, hi, lo);
+        const uint32_t p = ra.rseq & 1u;
+        const bool keeper = blockIdx.x == 0 && threadIdx.x == 0;
+        if (done_before != 0u && done_before < la.iter) {  // (== iter: workgroup 0 of THIS launch has just recorded its verdict)
+            if (keeper) {  // nothing was added since: the snapshot chain stays intact
+                scal->snap_hi[p] = hi;
+                scal->snap_lo[p] = lo;
+            }
+            return;
+        }
+        const double sum64 = residual_sum_f64(hi, lo, scal->snap_hi[p ^ 1u], scal->snap_lo[p ^ 1u]);
+        bool more = false;
+        if (la.enabled) {
+            // the host's operations: f64 sum rounded once, two f32 divisions, one product
+            const float sum = (float)sum64;
+            const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
+            if ((scal->flags & DF_NONFINITE) || !(fabsf(avg) <= 3.402823466e38f)) {
+                more = false;  // the reference panics (dfsph.rs:223 / :378); the host reports it
+            } else if (la.fixed) {
+                more = la.iter < la.fixed;
+            } else {
+                const float rel = DIVERGENCE ? avg : avg / la.rho0;  // dfsph.rs:222
+                more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
+                if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
+            }
+            last = !more;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            if (threadIdx.x == 0) {
+                scal->snap_hi[p] = hi;
+                scal->snap_lo[p] = lo;
+                ra.mb->err_sum = sum64;
+                if (la.enabled) {
+                    ra.mb->loop_hist[la.iter % LOOP_HIST] = sum64;
+                    __hip_atomic_store(&scal->loop_done, more ? 0u : la.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!more) {
+                        ra.mb->loop_iters = la.iter;
+                        __threadfence_system();
+                        __hip_atomic_store((uint32_t*)&ra.mb->loop_gen_done, la.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            publish_common(scal, ra.mb, ra.seq);
+        }
     }
     // staged neighbour records: WARM: {pos, v*} (+ the warm-start value of the neighbour); else PK = {pos, k, err}
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float warm_s[WARM ? STAGE_SLOTS : 1];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbStage S = nb_stage_of(nb, blk, n);
-    nb_stage_load(rec, WARM ? (const float4*)PV : PK, S, 0xFFFFFFFFu);
-    if (WARM) nb_stage_load(warm_s, (const float*)warm, S, soff);  // warm[] has no boundary tail; static entries do not use it
+    const NbHead h = nb_head(nb, blk, i, n);
+    const float4 pvi = i < n ? PV[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float warm_i = i < n ? warm[i] : 0.0f;
+    struct StageRec {
+        float4 r;
+        float w;
+    };
+    nb_stage(
+        h,
+        [&](uint32_t g) {
+            // warm[] has no boundary tail; static entries do not use it
+            if (WARM) return StageRec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : 0u)};
+            return StageRec{gat(PK, g), 0.0f};
+        },
+        [&](uint32_t slot, const StageRec& q) {
+            rec[slot] = q.r;
+            if (WARM) warm_s[slot] = q.w;
+        });
     __syncthreads();
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
-        const NbHead h = nb_head(nb, i);
         const uint32_t cd = h.cd, ct = h.ct;
-        const float4 pvi = PV[i];
         float ki;
         float2 ri;
         if (WARM) {
-            ki = 0.5f * fmaxf(warm[i], lim);
+            ki = 0.5f * fmaxf(warm_i, lim);
             ri = make_float2(pvi.x, pvi.y);
         } else {
-            const float4 pki = S.wide ? PK[i] : lds_read_f4(&rec[i - S.lw0]);
+            const float4 pki = h.wide ? PK[i] : lds_read_f4(&rec[i - h.lw0]);
             ki = pki.z;
             ri = make_float2(pki.x, pki.y);
         }
@@ -1639,23 +1774,18 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             dx = k < ct ? tx : dx;
             dy = k < ct ? ty : dy;
         };
-        if (S.wide)
-            nb_traverse<true>(
-                h, ct,
-                [&](uint32_t g) {
-                    // warm[] has no boundary tail; static entries do not use it
-                    if (WARM) return Rec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : i)};
-                    return Rec{gat(PK, g), 0.0f};
-                },
-                consume);
-        else
-            nb_traverse<false>(
-                h, ct,
-                [&](uint32_t slot) {
-                    if (WARM) return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&warm_s[slot])};
-                    return Rec{lds_read_f4(&rec[slot]), 0.0f};
-                },
-                consume);
+        nb_traverse(
+            h, ct,
+            [&](uint32_t slot) {
+                if (WARM) return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&warm_s[slot])};
+                return Rec{lds_read_f4(&rec[slot]), 0.0f};
+            },
+            [&](uint32_t g) {
+                // warm[] has no boundary tail; static entries do not use it
+                if (WARM) return Rec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : i)};
+                return Rec{gat(PK, g), 0.0f};
+            },
+            consume);
         float2 o;
         if (INV_DT) {
             o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
@@ -1665,11 +1795,11 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             o.y = pvi.w - dy * K.mass;
         }
         PV[i] = make_float4(pvi.x, pvi.y, o.x, o.y);
-        if (!WARM) warm[i] += ki;  // dfsph.rs:142 / :296
+        if (!WARM) warm[i] = warm_i + ki;  // dfsph.rs:142 / :296
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
     if (!WARM && INV_DT)
-        if (ca.hist && (!la.enabled || done == la.iter)) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
+        if (ca.hist && last) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1680,25 +1810,24 @@ __global__ __launch_bounds__(256) void k_export_counts(const uint32_t* __restric
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = counts[i];
-    out[2 * i] = (uint16_t)(c & 0xffffu);
-    out[2 * i + 1] = (uint16_t)((c >> 16) & 0x7fffu);
-    totals[i] = (c >> 16) & 0x7fffu;
+    out[2 * i] = (uint16_t)(c & 0x7fu);
+    out[2 * i + 1] = (uint16_t)((c >> 7) & 0x7fu);
+    totals[i] = (c >> 7) & 0x7fu;
 }
 // the reference's list content: sorted fluid index for dynamic entries, boundary index for static ones
 __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, const uint32_t* __restrict__ start, uint32_t n,
                                                        uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const NbHead h = nb_head(nb, i);
-    const NbStage S = nb_stage_of(nb, i >> 8, n);
+    const NbHead h = nb_head(nb, i >> 8, i, n);
     const uint32_t s = start[i];
     for (uint32_t k = 0; k < h.ct; ++k) {
         uint32_t g;
         if (h.wide) {
             g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
         } else {
-            const uint32_t slot = *(const uint16_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 2u));
-            g = slot < LIST_WIN ? S.lw0 + slot : S.rtab[slot - LIST_WIN];
+            const uint32_t slot = *(const uint16_t*)(h.rows + (k >> 2) * 512u + h.lane * 8u + (k & 3u) * 2u);
+            g = slot < LIST_WIN ? h.lw0 + slot : h.rtab[slot - LIST_WIN];
         }
         out[s + k] = g < soff ? g : g - soff;
     }
