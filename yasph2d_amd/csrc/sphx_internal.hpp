@@ -41,6 +41,7 @@ constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions 
 constexpr uint32_t LIST_HALO = SPHX_LIST_HALO;
 constexpr uint32_t LIST_WIN = 256 + 2 * LIST_HALO;
 constexpr uint32_t REMOTE_CAP = 512;
+constexpr uint32_t WAVE_REMOTE = REMOTE_CAP / 4;  // every wavefront of a workgroup owns a quarter of the table (its format is decided per wavefront)
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
 // internal device flag bits (DevScalars::flags)

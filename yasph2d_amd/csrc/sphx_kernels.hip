@@ -804,6 +804,32 @@ __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ b
     PK[soff + j] = r;
 }
 
+// In-kernel stamps (diagnostic builds only, -DSPHX_STAMPS: tools/ab_build.sh): cycles per phase, summed over wavefronts.  The
+// stamp values leave the kernel through g_stamp only; no result is computed from them.
+#ifdef SPHX_STAMPS
+__device__ unsigned long long g_stamp[16];
+#define SPHX_STAMP(k)                                                                                   \
+    {                                                                                                   \
+        unsigned long long t_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[k], t_ - stamp_prev_);                          \
+        stamp_prev_ = t_;                                                                               \
+    }
+#define SPHX_STAMP_BEGIN()                                                                              \
+    unsigned long long stamp_prev_;                                                                     \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[15], 1ull);                                     \
+    }
+#else
+#define SPHX_STAMP(k)
+#define SPHX_STAMP_BEGIN()
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // a5+a6 (+a8+a9 fused): neighbour lists.  neighborhood_search.rs:312-397 — candidates = particles of the 3x3 cell box visited
 // in ascending sorted index (= ascending Morton code of the 9 cells), accepted iff 1e-10 < d^2 <= h^2, dynamic first then
@@ -895,9 +921,15 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
     }
 }
 
-// 8 waves per SIMD = 8 workgroups per CU: 12 staged rows (12 KiB) + the window (6 KiB) keep a workgroup at 18 KiB of the CU's
-// 160 KiB, and the kernel fits the register budget of 64 without spills.  At 1 M particles the 3 906 workgroups then fit into two "rounds"
-// of the chip instead of 2.2 (16 rows / 7 waves: +3.5 us; 12 rows at 7 waves: no change — it is the occupancy that pays).
+// 8 waves per SIMD = 8 workgroups per CU: the staged rows (13 KiB) + the window (6 KiB) keep a workgroup below 20 KiB of the CU's
+// 160 KiB, and the kernel fits the register budget of 64.  At 1 M particles the 3 906 workgroups then fit into two "rounds" of the
+// chip.
+// The kernel is bound by the LENGTH of its chain of dependent memory round trips (each 1.5-3 us with every CU loading), not by
+// bytes or instructions (in-kernel stamps, profiles/r02_*): the chain is kept short —
+//   own position + window + directory + cell ranges are requested before the one barrier of the kernel;
+//   the candidate scan handles four candidates per trip, the density/alpha pass four neighbours per trip (out-of-window records
+//   are re-read from global memory in one batch per trip instead of one dependent load per candidate);
+//   the list format is decided per WAVEFRONT (no second barrier), the statistics are added per wavefront (no third one).
 #ifndef NB_BOUNDS
 #define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
@@ -908,9 +940,8 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
                                                          float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
-    __shared__ uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..15 of each wave, written out as whole 256-byte rows
-    __shared__ float2 win[256 + 2 * WIN_HALO + 1];  // positions of the sorted particles around this workgroup's 256 (+1: the
-                                                    // pipelined read one past a cell's last candidate stays inside the array)
+    __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
+    __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
@@ -918,64 +949,82 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     const uint32_t b0 = xcd_bid() * 256;
     const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
     const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
-    for (uint32_t t = threadIdx.x; t < wlen; t += 256) win[t] = posA[w0 + t];
+    SPHX_STAMP_BEGIN()
+    const bool live = i < n;
+    const float2 pi = posA[live ? i : b0];  // own position straight from global memory: the cell look-ups below do not wait for the barrier
+    constexpr uint32_t NWIN = (256 + 2 * WIN_HALO + 255) / 256;
+    float2 wreg[NWIN];
+#pragma unroll
+    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
+    uint32_t cx, cy;
+    cell_of(K, pi, cx, cy);
+    uint32_t slot[9], s[9], e[9];
+    bool maybe_static;
+    slots9(gd, cx, cy, slot, &maybe_static);
+    ranges9(gd, slot, s, e);
+#pragma unroll
+    for (uint32_t u = 0; u < NWIN; ++u)
+        if (threadIdx.x + u * 256u < wlen) win[threadIdx.x + u * 256u] = wreg[u];
     __syncthreads();
+    SPHX_STAMP(0)
     uint32_t cd = 0, ct = 0;
-    float2 pi = make_float2(0.0f, 0.0f);
-    if (i < n) {
-        pi = lds_read_f2(&win[i - w0]);
-        uint32_t cx, cy;
-        cell_of(K, pi, cx, cy);
+    uint32_t* const mytile = &tile[w][0][lane];
+    const uint32_t wlen_b = wlen * 8u;
+    if (live) {
         uint32_t flags = 0;
-        uint32_t* const mytile = &tile[w][0][lane];
-        // phase 1: filter.  The accept path is a single LDS store so the divergent candidate loop stays cheap.
-        uint32_t slot[9], s[9], e[9];
-        const uint32_t wlen_b = wlen * 8u;
-        bool maybe_static;
-        slots9(gd, cx, cy, slot, &maybe_static);
-        ranges9(gd, slot, s, e);
+        // phase 1: filter
+        SPHX_STAMP(1)
+#ifndef SPHX_ABL_NOLOOP
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // software pipeline: the next candidate's ds_read is in flight while the current one is tested.  The out-of-window
-            // re-read stays INSIDE the loop: per (lane, cell) it is rare, but some lane of a wave needs it for most cells, and a
-            // separate slow loop would then run after the fast one for nearly every wave (measured: +5 us).
-            // The kernel is VALU-bound and this loop is half of its instructions, so it is written for instruction count:
-            // * it runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), negative for j < w0; n < 2^28): the j is
-            //   only formed for accepted candidates;
-            // * two candidates per trip with the two position registers swapping roles, so the pipelined value is never copied;
-            // * the 64-entry cap is not tested here: entries past it are stored to a don't-care word and ct is clamped afterwards.
+            // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
+            // itself: an LDS round trip, five exec-mask branches and a vmcnt(0) wait per candidate.)  A cell holds ~3-4 particles, so
+            // a cell is usually one trip: four window reads in flight together, four distance tests, and an ORDERED branch-free
+            // append: every lane writes all four slots, the rejected ones to a dump row.
+            // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28);
+            // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
+            // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
             const uint32_t eb = (e[t] - w0) * 8u;
             uint32_t ab = (s[t] - w0) * 8u;
-            if (ab != eb) {
-                float2 p0 = lds_read_f2((const float2*)((const char*)win + min(ab, wlen_b))), p1;
-                auto test = [&](float2 pj) {
-                    if (ab >= wlen_b) pj = gat(posA, w0 + (uint32_t)((int32_t)ab >> 3));
+            while (ab != eb) {
+                const uint32_t left = (eb - ab) >> 3;  // >= 1
+                float2 pj[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) pj[u] = lds_read_f2((const float2*)((const char*)win + min(ab + 8u * u, wlen_b)));  // win[wlen]: pad slot
+#ifndef SPHX_ABL_NOFALLBACK  // (timing experiments: tools/ab_build.sh)
+                if (ab >= wlen_b || ab + 24u >= wlen_b) {  // the first (ab "negative": j < w0) or the last of the four lies outside the window
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        if (ab + 8u * u >= wlen_b && u < left) pj[u] = gat(posA, w0 + (uint32_t)((int32_t)(ab + 8u * u) >> 3));
+                }
+#endif
+                uint32_t c[5];
+                c[0] = ct;
+                bool acc[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
                     // both components in one packed instruction each (v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations, no fusion)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 d = f32x2{pj.x, pj.y} - f32x2{pi.x, pi.y};
+                    const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
                     const f32x2 q = d * d;
                     const float d2 = q.x + q.y;
-                    if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
-                        const uint32_t j = w0 + (uint32_t)((int32_t)ab >> 3);
-                        if (ct < STAGE_ROWS)
-                            mytile[ct * 64] = j;
-                        else
-                            *(ct < MAX_NEIGHBORS ? &list[ell_index(i, ct)] : &counts[i]) = j;  // counts[i] is written below
-                        ct += 1;
-                    }
-                };
-                for (;;) {
-                    p1 = lds_read_f2((const float2*)((const char*)win + min(ab + 8u, wlen_b)));  // win[wlen] is the pad slot; -8 + 8 = 0: a range may enter the window
-                    test(p0);
-                    ab += 8u;
-                    if (ab == eb) break;
-                    p0 = lds_read_f2((const float2*)((const char*)win + min(ab + 8u, wlen_b)));
-                    test(p1);
-                    ab += 8u;
-                    if (ab == eb) break;
+                    acc[u] = u < left && d2 <= K.radius_sq && d2 > 1.0e-10f;
+                    c[u + 1] = c[u] + (acc[u] ? 1u : 0u);
                 }
+                const uint32_t j0 = w0 + (uint32_t)((int32_t)ab >> 3);
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) mytile[(acc[u] ? min(c[u], STAGE_ROWS) : STAGE_ROWS) * 64u] = j0 + u;  // row STAGE_ROWS: dump
+                if (c[4] > STAGE_ROWS) {  // rare: rows past the staged ones live in global memory (32-bit, at their wide address)
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        if (acc[u] && c[u] >= STAGE_ROWS && c[u] < MAX_NEIGHBORS) list[ell_index(i, c[u])] = j0 + u;
+                }
+                ct = c[4];
+                ab += min(left, 4u) * 8u;
             }
         }
+#endif
+        SPHX_STAMP(2)
         ct = min(ct, MAX_NEIGHBORS);
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
@@ -1008,74 +1057,84 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
+        SPHX_STAMP(3)
     }
-    if (FUSE && i < n) {
-        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order
+#ifdef SPHX_ABL_NOPHASE2
+    if (false) {
+#else
+    if (FUSE && live) {
+#endif
+        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order,
+        // four neighbours per trip: their slots and positions are read together; the accumulation stays sequential
         float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
         float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-        for (uint32_t k = 0; k < ct; ++k) {
-            uint32_t j = lds_read_u32(&tile[w][min(k, STAGE_ROWS - 1u)][lane]);
-            if (k >= STAGE_ROWS) j = list[ell_index(i, k)];
-            const uint32_t wj = j - w0;  // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
-            float2 rj = lds_read_f2(&win[min(wj, wlen - 1u)]);
-            if (wj >= wlen) rj = gat(posA, j);
-            const float dx = rj.x - pi.x, dy = rj.y - pi.y;
-            const float r = sqrt_dist(dx * dx + dy * dy);
-            const float q = fminf(r * K.w_hinv, 1.0f);
-            const float omq = 1.0f - q;
-            const float omq_sq = omq * omq;
-            rho += (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
-            const float sg = K.w_ngrad * omq * omq * omq;
-            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-            gsx += gx;
-            gsy += gy;
-            gss += gx * gx + gy * gy;
+        for (uint32_t k0 = 0; k0 < ct; k0 += 4) {
+            uint32_t j[4];
+            float2 rj[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) j[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
+            if (k0 + 4u > STAGE_ROWS) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (k0 + u >= STAGE_ROWS && k0 + u < ct) j[u] = list[ell_index(i, k0 + u)];
+            }
+            // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
+            bool far = false;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t wj = j[u] - w0;
+                rj[u] = lds_read_f2(&win[min(wj, wlen)]);
+                far |= k0 + u < ct && wj >= wlen;
+            }
+            if (far) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (k0 + u < ct && j[u] - w0 >= wlen) rj[u] = gat(posA, j[u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const bool on = k0 + u < ct;
+                const float dx = rj[u].x - pi.x, dy = rj[u].y - pi.y;
+                const float r = sqrt_dist(dx * dx + dy * dy);
+                const float q = fminf(r * K.w_hinv, 1.0f);
+                const float omq = 1.0f - q;
+                const float omq_sq = omq * omq;
+                const float t_rho = rho + (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
+                const float sg = K.w_ngrad * omq * omq * omq;
+                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+                const float t_gsx = gsx + gx, t_gsy = gsy + gy, t_gss = gss + (gx * gx + gy * gy);
+                rho = on ? t_rho : rho;
+                gsx = on ? t_gsx : gsx;
+                gsy = on ? t_gsy : gsy;
+                gss = on ? t_gss : gss;
+            }
         }
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
         alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
     }
-    // ---- list format of this workgroup (NbHead) ------------------------------------------------------------------------------
+    SPHX_STAMP(4)
+    // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
     // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
     // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
-    // away in Morton order, or a boundary particle) gets the next free line r of this workgroup's out-of-window table and is stored
-    // as LIST_WIN + r.  Lines are handed out in a fixed order (wave, row, lane).  A workgroup with more than remote_cap such
-    // entries keeps 32-bit global slots (wide; its traversals gather from global memory).
+    // away in Morton order, or a boundary particle) gets the next free line r of this wavefront's quarter of the workgroup's
+    // out-of-window table and is stored as LIST_WIN + w * WAVE_REMOTE + r.  Lines are handed out in a fixed order (row, lane).  A
+    // wavefront with more than remote_cap / 4 such entries keeps 32-bit global slots (wide; its traversals gather from global memory).
     // 16-bit layout of a wave's slice: entries 4q .. 4q+3 of a lane are one 8-byte word at q * 512 + lane * 8, so a traversal
     // fetches the first twelve entries of its particle with three coalesced loads that depend on nothing.
-    __shared__ uint32_t wtot[4];
     const uint32_t lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     const uint32_t lwlen = min(b0 + 256u + LIST_HALO, n) - lw0;
+    const uint32_t cap = K.remote_cap / 4u;
     uint32_t m = min(ct, STAGE_ROWS);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     const bool spill = __any(ct > STAGE_ROWS);
-    // pass A: count the out-of-window entries
-    uint32_t wave_rem = 0, spill_rem = 0;
-    for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t g = lds_read_u32(&tile[w][k][lane]);
-        wave_rem += (uint32_t)__popcll(__ballot(k < ct && g - lw0 >= lwlen));
-    }
-    uint32_t spill_before = 0;  // out-of-window spill entries of lower lanes
-    if (spill) {
-        for (uint32_t k = STAGE_ROWS; k < ct; ++k) spill_rem += (list[ell_index(i, k)] - lw0 >= lwlen) ? 1u : 0u;
-        const uint32_t inc = wave_incl_scan(spill_rem);
-        spill_before = inc - spill_rem;
-        wave_rem += (uint32_t)__shfl((int)inc, 63, 64);
-    }
-    if (lane == 0) wtot[w] = wave_rem;
-    __syncthreads();
-    const uint32_t rtot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    uint32_t run = (w > 0 ? wtot[0] : 0u) + (w > 1 ? wtot[1] : 0u) + (w > 2 ? wtot[2] : 0u);
-    const bool wide = rtot > K.remote_cap || K.remote_cap == 0u;
-    uint32_t* const rtab = remote + (size_t)xcd_bid() * REMOTE_CAP;
-    if (i < n) counts[i] = nb_count_word(cd, ct, wide ? 0u : rtot, wide);
-    // pass B: rows out, coalesced (lanes past their own count write don't-care values)
-    if (wide) {
-        const size_t row0 = (size_t)(i >> 6) * 64;
-        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = lds_read_u32(&tile[w][k][lane]);
-    } else {
-        char* const slice = (char*)(list + (size_t)(i >> 6) * 4096);
-        const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t* const rtab = remote + (size_t)xcd_bid() * REMOTE_CAP + w * WAVE_REMOTE;
+    char* const slice = (char*)(list + (size_t)(i >> 6) * 4096);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // optimistic single pass: 16-bit rows and table lines go out while the lines are counted; a wavefront that overflows its quarter
+    // of the table (rare) rewrites its rows as 32-bit ones afterwards
+    uint32_t run = 0;
+    if (cap) {
         uint32_t packed[2] = {0u, 0u};
         for (uint32_t k = 0; k < m; ++k) {
             const uint32_t g = lds_read_u32(&tile[w][k][lane]);
@@ -1083,41 +1142,51 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
             const unsigned long long mask = __ballot(rem);
             const uint32_t r = run + (uint32_t)__popcll(mask & below);
             run += (uint32_t)__popcll(mask);
-            if (rem) rtab[r] = g;
-            const uint32_t slot = (rem ? LIST_WIN + r : g - lw0) & 0xffffu;
+            if (rem && r < WAVE_REMOTE) rtab[r] = g;
+            const uint32_t sl = (rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0) & 0xffffu;
             const uint32_t q = k & 3u;
-            if (q == 0u) packed[0] = slot;
-            if (q == 1u) packed[0] |= slot << 16;
-            if (q == 2u) packed[1] = slot;
-            if (q == 3u) packed[1] |= slot << 16;
+            if (q == 0u) packed[0] = sl;
+            if (q == 1u) packed[0] |= sl << 16;
+            if (q == 2u) packed[1] = sl;
+            if (q == 3u) packed[1] |= sl << 16;
             if (q == 3u || k + 1u == m) *(uint2*)(slice + (k >> 2) * 512u + lane * 8u) = make_uint2(packed[0], packed[1]);
         }
-        if (spill) {
-            // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address, byte
-            // 256 k + 4 lane); their 16-bit home, byte 128 (k & ~3) + 8 lane + 2 (k & 3), lies below every 32-bit row >= k, so
-            // rewriting in ascending k never overwrites an entry still to be read
-            uint32_t r = run + spill_before;
-            for (uint32_t k = STAGE_ROWS; k < ct; ++k) {
-                const uint32_t g = list[ell_index(i, k)];
-                const bool rem = g - lw0 >= lwlen;
-                if (rem) rtab[r] = g;
-                *(uint16_t*)(slice + (k >> 2) * 512u + lane * 8u + (k & 3u) * 2u) = (uint16_t)(rem ? LIST_WIN + r : g - lw0);
-                r += rem ? 1u : 0u;
-            }
+    }
+    uint32_t spill_rem = 0, spill_before = 0;
+    if (spill) {
+        for (uint32_t k = STAGE_ROWS; k < ct; ++k) spill_rem += (list[ell_index(i, k)] - lw0 >= lwlen) ? 1u : 0u;
+        const uint32_t inc = wave_incl_scan(spill_rem);
+        spill_before = inc - spill_rem;
+        spill_rem = (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    const uint32_t rtot = run + spill_rem;
+    const bool wide = cap == 0u || rtot > cap;
+    if (live) counts[i] = nb_count_word(cd, ct, wide ? 0u : rtot, wide);
+    if (wide) {
+        // entries past the staged rows already sit at their 32-bit address
+        const size_t row0 = (size_t)(i >> 6) * 64;
+        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = lds_read_u32(&tile[w][k][lane]);
+    } else if (spill) {
+        // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address, byte
+        // 256 k + 4 lane); their 16-bit home, byte 128 (k & ~3) + 8 lane + 2 (k & 3), lies below every 32-bit row >= k, so
+        // rewriting in ascending k never overwrites an entry still to be read
+        uint32_t r = run + spill_before;
+        for (uint32_t k = STAGE_ROWS; k < ct; ++k) {
+            const uint32_t g = list[ell_index(i, k)];
+            const bool rem = g - lw0 >= lwlen;
+            if (rem) rtab[r] = g;
+            *(uint16_t*)(slice + (k >> 2) * 512u + lane * 8u + (k & 3u) * 2u) = (uint16_t)(rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0);
+            r += rem ? 1u : 0u;
         }
     }
-
-    // total number of list entries and of out-of-window entries (stats only): block reduce, striped atomics per workgroup
+    SPHX_STAMP(5)
+    // total number of list entries and of out-of-window entries (stats only): one pair of striped atomics per wavefront
     unsigned long long tot = ct;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) tot += __shfl_down(tot, d, 64);
-    __shared__ unsigned long long ws[4];
-    if (lane == 0) ws[w] = tot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];
-        if (t) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, t);
-        if (rtot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
+    if (lane == 0) {
+        if (tot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, tot);
+        if (rtot && !wide) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
     }
 }
 
@@ -1156,64 +1225,61 @@ __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_
 // requested before anything is waited for.
 struct NbHead {
     uint32_t cd, ct;      // NeighborRange: dynamic / total neighbours
-    uint32_t R;           // entries of the workgroup's out-of-window table (0 when wide)
-    bool wide;            // lists hold 32-bit global slots, nothing is staged (workgroup-uniform)
+    uint32_t R;           // entries of this wavefront's quarter of the out-of-window table (0 when wide)
+    bool wide;            // this wavefront's lists hold 32-bit global slots (wave-uniform)
     uint2 e[NB_G0];       // entries 0..11, four 16-bit staging slots per word pair (narrow format)
     const char* rows;     // this wave's 16 KiB slice of the list buffer
     uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
-    const uint32_t* rtab;
+    const uint32_t* rtab; // this wavefront's quarter of the workgroup's table
 };
 __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
     NbHead h;
     const uint32_t b0 = blk * 256u;
     const bool active = b0 < n;  // the grid is rounded up: workgroups past the last particle have no lists
-    // lanes past n (last workgroup) read the format of their workgroup from its first particle
-    const uint32_t c = active ? nb.counts[i < n ? i : b0] : 0u;
-    h.cd = i < n ? c & 0x7fu : 0u;
-    h.ct = i < n ? (c >> 7) & 0x7fu : 0u;
+    const uint32_t c = i < n ? nb.counts[i] : 0u;
+    h.cd = c & 0x7fu;
+    h.ct = (c >> 7) & 0x7fu;
+    // format and table size are wave-uniform: taken from the wave's first lane (a wave wholly past n: no entries, nothing staged)
     h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
-    h.R = h.wide ? 0u : min((uint32_t)__builtin_amdgcn_readfirstlane((c >> 14) & 0x3ffu), REMOTE_CAP);
+    h.R = h.wide ? 0u : min((uint32_t)__builtin_amdgcn_readfirstlane((c >> 14) & 0x3ffu), WAVE_REMOTE);
     h.lane = i & 63u;
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
 #pragma unroll
     for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
     h.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
-    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP;
+    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
     return h;
 }
 // Fill the staging area: load(g) -> record of slot g of the [N|B] arrays (any type), store(slot, record) writes it to LDS.  Every
 // load of a thread is issued before the first store (the loads of the out-of-window lines wait for nothing but the table lines
-// and the count word, which were requested first).  Called by all 256 threads; the caller places the barrier.
+// and the count word, which were requested first).  The window is staged by all 256 threads together, a wavefront's quarter of the
+// table by that wavefront (only its own lists point there).  The caller places the barrier.
 template <class L, class S>
 __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
-    if (h.wide || h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
-    constexpr uint32_t NW = LIST_WIN / 256, NR = REMOTE_CAP / 256;
+    if (h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
+    constexpr uint32_t NW = LIST_WIN / 256, NR = WAVE_REMOTE / 64;
+    const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
     uint32_t g[NR];
 #pragma unroll
-    for (uint32_t u = 0; u < NR; ++u) g[u] = h.rtab[threadIdx.x + u * 256u];  // lines past R: don't-care
+    for (uint32_t u = 0; u < NR; ++u) g[u] = h.rtab[lane + u * 64u];  // lines past R: don't-care
     decltype(load(0u)) wrec[NW], rrec[NR];
 #pragma unroll
     for (uint32_t u = 0; u < NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;
-        wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads (lwlen >= 1 here)
+        wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads
     }
 #pragma unroll
-    for (uint32_t u = 0; u < NR; ++u) {
-        const uint32_t t = threadIdx.x + u * 256u;
-        rrec[u] = load(t < h.R ? g[u] : h.lw0);
-    }
+    for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
 #pragma unroll
     for (uint32_t u = 0; u < NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;
         if (t < h.lwlen) store(t, wrec[u]);
     }
 #pragma unroll
-    for (uint32_t u = 0; u < NR; ++u) {
-        const uint32_t t = threadIdx.x + u * 256u;
-        if (t < h.R) store(LIST_WIN + t, rrec[u]);
-    }
+    for (uint32_t u = 0; u < NR; ++u)
+        if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, rrec[u]);
 }
 // Traversal of entries 0..lim-1 in list order.  gather(x) -> record: x = staging slot (narrow) or global slot (wide);
 // consume(record, k) must ignore k >= lim.
@@ -1406,11 +1472,14 @@ __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restri
         if (t & 0xffffffffull) atomicAdd(&st->res_lo, t & 0xffffffffull);
     }
 }
-// called by a whole wavefront; every lane returns the cumulative sums
-__device__ __forceinline__ void wave_residual_total(const DevScalars* __restrict__ scal, unsigned long long& hi, unsigned long long& lo) {
+// called by a whole wavefront, in two steps so that the reader's own loads can be requested in between: (1) every lane requests
+// one stripe, (2) every lane gets the cumulative sums
+__device__ __forceinline__ void residual_stripe_load(const DevScalars* __restrict__ scal, unsigned long long& hi, unsigned long long& lo) {
     const uint32_t lane = threadIdx.x & 63u;
     hi = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     lo = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+}
+__device__ __forceinline__ void residual_wave_reduce(unsigned long long& hi, unsigned long long& lo) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         hi += __shfl_xor(hi, d, 64);
@@ -1482,6 +1551,10 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
 // derives the step the host's TimeManager will arrive at from it (TimerLaw), workgroup 0 publishes vmax and dt.
 __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt,
                                                   DevScalars* __restrict__ scal, VmaxArgs va, TimerLaw law) {
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    const uint32_t il = min(i, n - 1u);  // (n >= 1: the launch sites skip empty particle sets)
+    float4 pv = PV[il];  // requested before the reduction is read: one round trip, not two
+    const float2 a = accel[il];
     if (va.enabled) {
         const uint32_t b = wave_vmax_get(scal, va.vslot);
         unsigned long long ns = 0;
@@ -1491,10 +1564,7 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
         }
         if (blockIdx.x == 0 && threadIdx.x < 64) vmax_publish(scal, va, b, law, ns, dt);
     }
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
-    float4 pv = PV[i];
-    const float2 a = accel[i];
     pv.z = pv.z + a.x * dt;
     pv.w = pv.w + a.y * dt;
     PV[i] = pv;
@@ -1671,56 +1741,24 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
     }
     // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs):
     // every workgroup derives the same sum and — in a device-run loop (LoopArgs) — the same verdict of dfsph.rs:221-236 / :376-391;
-    // workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox.
-    bool last = true;  // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
-    if (!WARM && ra.enabled) {
-        constexpr bool DIVERGENCE = !INV_DT;
+    // workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox.  The stripes
+    // are requested first and reduced after the staging barrier, so they cost no round trip of their own.
+    constexpr bool RES = !WARM;
+    unsigned long long hi = 0, lo = 0;
+    const uint32_t rp = ra.rseq & 1u;
+    if (RES && ra.enabled) {
         // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
         const uint32_t done_before = (la.enabled && la.iter > 1u) ? scal->loop_done : 0u;
-        unsigned long long hi, lo;
-        wave_residual_total(scal, hi, lo);
-        const uint32_t p = ra.rseq & 1u;
-        const bool keeper = blockIdx.x == 0 && threadIdx.x == 0;
+        residual_stripe_load(scal, hi, lo);
         if (done_before != 0u && done_before < la.iter) {  // (== iter: workgroup 0 of THIS launch has just recorded its verdict)
-            if (keeper) {  // nothing was added since: the snapshot chain stays intact
-                scal->snap_hi[p] = hi;
-                scal->snap_lo[p] = lo;
-            }
-            return;
-        }
-        const double sum64 = residual_sum_f64(hi, lo, scal->snap_hi[p ^ 1u], scal->snap_lo[p ^ 1u]);
-        bool more = false;
-        if (la.enabled) {
-            // the host's operations: f64 sum rounded once, two f32 divisions, one product
-            const float sum = (float)sum64;
-            const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
-            if ((scal->flags & DF_NONFINITE) || !(fabsf(avg) <= 3.402823466e38f)) {
-                more = false;  // the reference panics (dfsph.rs:223 / :378); the host reports it
-            } else if (la.fixed) {
-                more = la.iter < la.fixed;
-            } else {
-                const float rel = DIVERGENCE ? avg : avg / la.rho0;  // dfsph.rs:222
-                more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
-                if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
-            }
-            last = !more;
-        }
-        if (blockIdx.x == 0 && threadIdx.x < 64) {
-            if (threadIdx.x == 0) {
-                scal->snap_hi[p] = hi;
-                scal->snap_lo[p] = lo;
-                ra.mb->err_sum = sum64;
-                if (la.enabled) {
-                    ra.mb->loop_hist[la.iter % LOOP_HIST] = sum64;
-                    __hip_atomic_store(&scal->loop_done, more ? 0u : la.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!more) {
-                        ra.mb->loop_iters = la.iter;
-                        __threadfence_system();
-                        __hip_atomic_store((uint32_t*)&ra.mb->loop_gen_done, la.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
+            if (blockIdx.x == 0 && threadIdx.x < 64) {  // nothing was added since: the snapshot chain stays intact
+                residual_wave_reduce(hi, lo);
+                if (threadIdx.x == 0) {
+                    scal->snap_hi[rp] = hi;
+                    scal->snap_lo[rp] = lo;
                 }
             }
-            publish_common(scal, ra.mb, ra.seq);
+            return;
         }
     }
     // staged neighbour records: WARM: {pos, v*} (+ the warm-start value of the neighbour); else PK = {pos, k, err}
@@ -1747,6 +1785,45 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             if (WARM) warm_s[slot] = q.w;
         });
     __syncthreads();
+    bool last = true;  // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
+    if (RES && ra.enabled) {
+        constexpr bool DIVERGENCE = !INV_DT;
+        residual_wave_reduce(hi, lo);
+        const double sum64 = residual_sum_f64(hi, lo, scal->snap_hi[rp ^ 1u], scal->snap_lo[rp ^ 1u]);
+        bool more = false;
+        if (la.enabled) {
+            // the host's operations: f64 sum rounded once, two f32 divisions, one product
+            const float sum = (float)sum64;
+            const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
+            if ((scal->flags & DF_NONFINITE) || !(fabsf(avg) <= 3.402823466e38f)) {
+                more = false;  // the reference panics (dfsph.rs:223 / :378); the host reports it
+            } else if (la.fixed) {
+                more = la.iter < la.fixed;
+            } else {
+                const float rel = DIVERGENCE ? avg : avg / la.rho0;  // dfsph.rs:222
+                more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
+                if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
+            }
+            last = !more;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            if (threadIdx.x == 0) {
+                scal->snap_hi[rp] = hi;
+                scal->snap_lo[rp] = lo;
+                ra.mb->err_sum = sum64;
+                if (la.enabled) {
+                    ra.mb->loop_hist[la.iter % LOOP_HIST] = sum64;
+                    __hip_atomic_store(&scal->loop_done, more ? 0u : la.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!more) {
+                        ra.mb->loop_iters = la.iter;
+                        __threadfence_system();
+                        __hip_atomic_store((uint32_t*)&ra.mb->loop_gen_done, la.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            publish_common(scal, ra.mb, ra.seq);
+        }
+    }
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
         const uint32_t cd = h.cd, ct = h.ct;
@@ -1827,7 +1904,7 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
             g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
         } else {
             const uint32_t slot = *(const uint16_t*)(h.rows + (k >> 2) * 512u + h.lane * 8u + (k & 3u) * 2u);
-            g = slot < LIST_WIN ? h.lw0 + slot : h.rtab[slot - LIST_WIN];
+            g = slot < LIST_WIN ? h.lw0 + slot : nb.remote[(size_t)(i >> 8) * REMOTE_CAP + (slot - LIST_WIN)];
         }
         out[s + k] = g < soff ? g : g - soff;
     }
