@@ -1739,17 +1739,22 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         dt = *dt_dev;
         inv_dt = 1.0f / dt;
     }
-    // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs):
-    // every workgroup derives the same sum and — in a device-run loop (LoopArgs) — the same verdict of dfsph.rs:221-236 / :376-391;
-    // workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox.  The stripes
-    // are requested first and reduced after the staging barrier, so they cost no round trip of their own.
+    // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs).
+    // Who needs it: workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox;
+    // in a device-run loop (LoopArgs) the density correction of every workgroup needs the verdict of dfsph.rs:221-236 (is this the
+    // last iteration?  then it also does the re-grid's advection + cell count).  One wavefront per workgroup derives it (every
+    // workgroup the same value) and hands it to the others through LDS behind the staging barrier; the stripes are requested
+    // first and reduced late, so they cost no round trip of their own.
     constexpr bool RES = !WARM;
+    const bool need_verdict = RES && ra.enabled && (blockIdx.x == 0 || (INV_DT && la.enabled && ca.hist != nullptr));
+    const bool judge = need_verdict && threadIdx.x < 64;
+    __shared__ uint32_t last_s;
     unsigned long long hi = 0, lo = 0;
     const uint32_t rp = ra.rseq & 1u;
     if (RES && ra.enabled) {
         // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
         const uint32_t done_before = (la.enabled && la.iter > 1u) ? scal->loop_done : 0u;
-        residual_stripe_load(scal, hi, lo);
+        if (judge) residual_stripe_load(scal, hi, lo);
         if (done_before != 0u && done_before < la.iter) {  // (== iter: workgroup 0 of THIS launch has just recorded its verdict)
             if (blockIdx.x == 0 && threadIdx.x < 64) {  // nothing was added since: the snapshot chain stays intact
                 residual_wave_reduce(hi, lo);
@@ -1784,9 +1789,7 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             rec[slot] = q.r;
             if (WARM) warm_s[slot] = q.w;
         });
-    __syncthreads();
-    bool last = true;  // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
-    if (RES && ra.enabled) {
+    if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
         residual_wave_reduce(hi, lo);
         const double sum64 = residual_sum_f64(hi, lo, scal->snap_hi[rp ^ 1u], scal->snap_lo[rp ^ 1u]);
@@ -1804,9 +1807,9 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
                 more = !(rel * dt < la.tol);                         // dfsph.rs:226 / :381
                 if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
             }
-            last = !more;
         }
-        if (blockIdx.x == 0 && threadIdx.x < 64) {
+        if (threadIdx.x == 0) last_s = more ? 0u : 1u;
+        if (blockIdx.x == 0) {
             if (threadIdx.x == 0) {
                 scal->snap_hi[rp] = hi;
                 scal->snap_lo[rp] = lo;
@@ -1824,6 +1827,9 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             publish_common(scal, ra.mb, ra.seq);
         }
     }
+    __syncthreads();
+    // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
+    const bool last = (need_verdict && la.enabled) ? last_s != 0u : true;
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
         const uint32_t cd = h.cd, ct = h.ct;
