@@ -18,6 +18,7 @@
 #ifndef SPHX_H
 #define SPHX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -220,6 +221,65 @@ int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* df
 int sphx_sub_iteration(sphx_ctx* ctx, int divergence, float dt, int first, double* out_err_sum, uint64_t* out_n_owned); /* :217-221 / :372-377 */
 int sphx_sub_advect(sphx_ctx* ctx, float dt);                              /* dfsph.rs:499-510 */
 
+
+/* ---- multi-GPU solver behind the Solver boundary ("device list ... internally may drive 1-8 GPUs") ----------------
+ * The reference's caller holds ONE Box<dyn Solver> (main.rs:50) and calls simulation_step(&mut world, &mut time_manager)
+ * (solver/mod.rs:12-18, main.rs:279).  sphx_multi is that one object over several GPUs: it cuts the domain into tiles (strips along
+ * the longer side; 2 x N/2 rectangles on 4 tiles), owns one context per tile and runs the whole tile step loop — ring-budget halo,
+ * one exchange per step, adaptive band, re-partitioning — inside the library.  Same two-phase step as sphx_step_begin/finish. */
+typedef struct sphx_multi sphx_multi;
+enum { SPHX_LAYOUT_AUTO = 0, SPHX_LAYOUT_STRIPS = 1, SPHX_LAYOUT_GRID = 2 };
+typedef struct sphx_multi_options {
+    uint32_t halo_cells;       /* widest ghost band in cells (16); the band in use follows the ring budget unless fixed_halo */
+    uint32_t fixed_halo;       /* 1: always exchange the full band */
+    uint32_t rebalance_every;  /* steps between re-partitions of the cuts (16; 0 = never) */
+    uint32_t layout;           /* SPHX_LAYOUT_* (auto: 2x2 on 4 tiles, strips otherwise) */
+    uint32_t cap_records;      /* records per halo buffer (0 = estimated from the uploaded scene) */
+    uint32_t reserved[3];
+} sphx_multi_options;
+/* Communicator supplied by the caller for one tile of a multi-process run (NULL: the built-in one — grouped ncclSend/ncclRecv over
+ * RCCL for the halo records, the shared-memory all-reduce below for the scalars).  exchange: send d_send[k] to rank peers[k] and
+ * receive d_recv[k] from it, `bytes` each, DEVICE buffers, ordered on hip_stream (no host synchronisation required of the caller's
+ * caller).  allreduce: op 0 = sum, 1 = max over n <= 8 doubles; every rank must receive the same bits. */
+typedef struct sphx_comm_ops {
+    void* user;
+    int rank, world;
+    int (*exchange)(void* user, const int* peers, int n_peers, void* const* d_send, void* const* d_recv, size_t bytes, void* hip_stream);
+    int (*allreduce)(void* user, const double* in, int n, int op, double* out);
+} sphx_comm_ops;
+typedef struct sphx_multi_info_t {
+    uint32_t world, local_tiles, halo_now, halo_max, peers, n_local, cap_records, grid_layout;
+    int32_t axis;
+    uint32_t reserved;
+    uint64_t exchanges, rebalances;
+    char transport[96];
+} sphx_multi_info_t;
+int sphx_multi_default_options(sphx_multi_options* out);
+/* all tiles in this process: tile r runs on HIP device devices[r] (a device may appear more than once); one host thread per tile */
+int sphx_multi_create(const sphx_params* params, const int* devices, int n_devices, const sphx_multi_options* opt, sphx_multi** out);
+/* ONE tile (rank of world) of a one-process-per-GPU run; comm == NULL: built-in RCCL + shared memory, `job` names the shared segment
+ * (unique per run, e.g. the rendezvous port) */
+int sphx_multi_create_rank(const sphx_params* params, int device, const sphx_comm_ops* comm, const char* job, int rank, int world,
+                           const sphx_multi_options* opt, sphx_multi** out);
+void sphx_multi_destroy(sphx_multi* m);
+const char* sphx_multi_last_error(const sphx_multi* m); /* m may be NULL: the last creation error */
+/* optional explicit cuts (cells) instead of the particle-count quantiles of the uploaded scene: strips along axis, or nx columns
+ * (xcuts[nx+1]) each cut again at its own ycuts[ix*(ny+1) ..] */
+int sphx_multi_set_layout(sphx_multi* m, int axis, const uint32_t* cuts, uint32_t n_cuts);
+int sphx_multi_set_grid_layout(sphx_multi* m, uint32_t nx, uint32_t ny, const uint32_t* xcuts, const uint32_t* ycuts);
+int sphx_multi_set_boundary(sphx_multi* m, const float* xy, uint32_t n);  /* the GLOBAL boundary; every tile clips its part */
+/* the GLOBAL particle arrays (every rank of a multi-process run passes the same ones; ids == NULL: 0..n-1); includes the warm-up
+ * block of dfsph.rs:419-428 */
+int sphx_multi_upload(sphx_multi* m, const float* pos_xy, const float* vel_xy, const uint32_t* ids, uint32_t n);
+int sphx_multi_clear_cached(sphx_multi* m);                                           /* Solver::clear_cached_data */
+int sphx_multi_step_begin(sphx_multi* m, float dt_prev, float* out_vmax);             /* dfsph.rs:419-477, vmax over ALL tiles */
+int sphx_multi_step_finish(sphx_multi* m, float dt, sphx_step_stats* out_stats);      /* dfsph.rs:484-524 */
+int sphx_multi_synchronize(sphx_multi* m);
+uint64_t sphx_multi_num_owned(const sphx_multi* m);
+/* owned particles of the local tiles (in-process: all particles), tile after tile; *inout_n: capacity in, count out */
+int sphx_multi_download(sphx_multi* m, float* pos_xy, float* vel_xy, float* density, uint32_t* ids, uint64_t* inout_n);
+int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out);
+sphx_ctx* sphx_multi_tile_ctx(sphx_multi* m, uint32_t local_tile); /* inspection (neighbours, cells, profiling) */
 
 /* ---- single-node scalar reductions through POSIX shared memory ---------------------------------------------------------------
  * The three per-step scalars of the tile driver (vmax, two residual sums) already sit in host memory (pinned mailbox) on every

@@ -1,0 +1,178 @@
+"""sphx_multi — the tile step loop inside libsphx (csrc/sphx_tiles.cpp) — against the reference implementation of the same loop:
+yasph2d_amd/tiles.py driving the CPU oracle (tests/tile_oracle_backend.py).  Same cuts, same halo rules, same re-partitioning:
+every owned particle must agree BIT FOR BIT, as must iteration counts, dt, the number of halo exchanges and the final cuts.
+
+  * all tiles in one process (sphx_multi_create: one host thread + HIP stream per tile, peer copies ordered by events);
+  * one process per tile (sphx_multi_create_rank) with a caller-supplied communicator over torch.distributed/gloo;
+  * the built-in RCCL transport is brought up with one rank (RCCL refuses two ranks on the one GPU of this box — gpurun_out/
+    r02_probe1/rccl_same_gpu.log: "Duplicate GPU detected" — so its multi-rank send/recv cannot be exercised here).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from test_tiles_cpu import GridLayout, run_tiles_threaded
+from util import assert_bits_equal, dam_break
+
+import yasph2d_amd as y
+from yasph2d_amd import _lib
+from yasph2d_amd.multi import MultiSolver
+from yasph2d_amd.tiles import cell_coord, quantile_cuts
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def oracle_tiles(pos, boundary, world, axis, steps, **kw):
+    from tile_oracle_backend import OracleTileBackend
+
+    out, cuts = run_tiles_threaded(lambda r: OracleTileBackend(), pos, boundary, world, axis, steps, **kw)
+    return out, list(run_tiles_threaded.final_cuts)
+
+
+def by_id(d):
+    o = np.argsort(d["ids"])
+    return {k: v[o] for k, v in d.items()}
+
+
+def merged_oracle(out):
+    parts = [o[0] for o in out]
+    d = {k: np.concatenate([p[k] for p in parts]) for k in ("ids", "pos", "vel", "density")}
+    return by_id(d)
+
+
+def compare(m_out, o_out, stats_m, stats_o):
+    a, b = by_id(m_out), merged_oracle(o_out)
+    np.testing.assert_array_equal(a["ids"], b["ids"])
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+    for sm, so in zip(stats_m, stats_o):
+        assert (sm["density_iterations"], sm["divergence_iterations"], sm["dt_ns"]) == (so["density_iterations"], so["divergence_iterations"], so["dt_ns"])
+
+
+@pytest.mark.parametrize("world,axis,halo,fixed,steps", [(2, 1, 16, (0, 0), 120), (3, 1, 8, (0, 0), 60), (2, 0, 6, (0, 0), 60), (2, 1, 10, (3, 2), 80)])
+def test_in_process_strips_bit_exact_vs_reference_loop(world, axis, halo, fixed, steps):
+    pos, boundary = dam_break(1.0)
+    cuts = quantile_cuts(cell_coord(pos, axis), world)
+    o, _ = oracle_tiles(pos, boundary, world, axis, steps, halo=halo, fixed=fixed, cuts=cuts, adaptive_halo=True, rebalance_every=8)
+    m = MultiSolver(y.default_params(fixed_iterations=fixed), devices=[0] * world, halo=halo, rebalance_every=8)
+    m.set_strips(axis, cuts)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    timer = y.TimeManager()
+    stats = [m.step(timer) for _ in range(steps)]
+    compare(m.download(), o, stats, o[0][1])
+    assert m.info()["exchanges"] == o[0][2]
+    assert m.info()["transport"].startswith("in-process")
+
+
+def test_in_process_2x2_through_the_impact_bit_exact_vs_reference_loop():
+    """SURVEY.md 8(e) "4 GPUs: 2x2 tiles": warm starts, diagonal migration, budget-triggered extra exchanges, re-partitioning."""
+    pos, boundary = dam_break(2.0)
+    lay = GridLayout.quantile(pos, 2, 2)
+    kw = dict(halo=10, fixed=(3, 2), rebalance_every=4, layout=lambda: GridLayout(lay.xcuts, lay.ycuts), adaptive_halo=True)
+    o, final = oracle_tiles(pos, boundary, 4, None, 150, **kw)
+    m = MultiSolver(y.default_params(fixed_iterations=(3, 2)), devices=[0, 0, 0, 0], halo=10, rebalance_every=4)
+    m.set_grid(lay.xcuts, lay.ycuts)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    timer = y.TimeManager()
+    stats = [m.step(timer) for _ in range(150)]
+    compare(m.download(), o, stats, o[0][1])
+    info = m.info()
+    assert info["exchanges"] == o[0][2] and info["rebalances"] == final[0][1] > 3 and info["grid_layout"] == 1
+
+
+def test_automatic_layout_is_the_quantile_layout():
+    """No cuts given: strips along the longer side at particle-count quantiles (2x2 on four tiles), like bench.py chose them."""
+    pos, boundary = dam_break(1.5)
+    for world in (2, 4):
+        m = MultiSolver(y.default_params(), devices=[0] * world, halo=8)
+        m.set_boundary(boundary)
+        m.upload(pos)
+        timer = y.TimeManager()
+        for _ in range(5):
+            m.step(timer)
+        d = m.download()
+        assert np.array_equal(np.sort(d["ids"]), np.arange(len(pos), dtype=np.uint32))
+        assert m.info()["grid_layout"] == (1 if world == 4 else 0)
+        m.close()
+
+
+def test_one_process_per_tile_over_a_caller_supplied_communicator(tmp_path):
+    """Two processes share the GPU; the library's step loop calls back into torch.distributed (gloo) for the halo records.  Same bits
+    as the two tiles held in one process."""
+    steps, scale = 60, 1.0
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(HERE, "multi_rank_worker.py"), str(tmp_path), str(steps), str(scale), "0", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    ranks = by_id({k: np.concatenate([r[0][k], r[1][k]]) for k in ("ids", "pos", "vel", "density")})
+    pos, boundary = dam_break(scale)
+    m = MultiSolver(y.default_params(), devices=[0, 0], halo=10, rebalance_every=4)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    timer = y.TimeManager()
+    stats = [m.step(timer) for _ in range(steps)]
+    local = by_id(m.download())
+    np.testing.assert_array_equal(ranks["ids"], local["ids"])
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(ranks[k], local[k], k)
+    assert [s["dt_ns"] for s in stats] == r[0]["dt_ns"].tolist() == r[1]["dt_ns"].tolist()
+    assert int(r[0]["exchanges"]) == m.info()["exchanges"]
+
+
+def test_builtin_rccl_transport_comes_up(monkeypatch):
+    """sphx_multi_create_rank without a communicator: shared-memory segment + RCCL loaded at run time (dlopen, ncclGetUniqueId,
+    ncclCommInitRank).  One rank is all this box allows; the step loop then runs through the same code path with no peers."""
+    monkeypatch.setenv("SPHX_RCCL_ALWAYS", "1")
+    pos, boundary = dam_break(1.0)
+    m = MultiSolver.rank(y.default_params(), 0, 0, 1, comm=None, job="pytest-rccl")
+    assert "RCCL" in m.info()["transport"]
+    m.set_boundary(boundary)
+    m.upload(pos)
+    timer = y.TimeManager()
+    for _ in range(20):
+        m.step(timer)
+    d = m.download()
+    assert len(d["ids"]) == len(pos) and np.isfinite(d["pos"]).all()
+    # one tile, no cuts: the same particles as the single context until the first warm start (tile mode lets kappa travel)
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    t2 = y.TimeManager()
+    for _ in range(20):
+        vmax = ctx.step_begin(t2.simulation_step())
+        ctx.step_finish(y.duration_as_secs_f32(t2.update_simulation_step(np.float32(0.01), vmax)))
+    s = ctx.download()
+    a, b = by_id(d), by_id(dict(ids=s["ids"], pos=s["pos"], vel=s["vel"], density=s["density"]))
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+
+
+def test_errors_are_reported_not_thrown():
+    L = _lib.lib()
+    assert L.sphx_multi_create(None, None, 0, None, None) == _lib.ERR_INVALID_ARGUMENT
+    m = MultiSolver(y.default_params(), devices=[0, 0], halo=16)
+    pos, boundary = dam_break(1.0)
+    m.set_boundary(boundary)
+    with pytest.raises(y.SphxError):
+        m.set_strips(0, [0, 10, 20, 65536])  # three tiles for a two-tile solver
+    with pytest.raises(y.SphxError):
+        m.step_finish(0.001)  # no step open
+    m.set_strips(1, [0, 5060, 5070, 65536][:3])
+    m.upload(pos)
+    with pytest.raises(y.SphxError):
+        m.step_finish(0.001)
+    v = m.step_begin(1.0 / 360.0)
+    with pytest.raises(y.SphxError):
+        m.step_begin(1.0 / 360.0)  # twice
+    with pytest.raises(y.SphxError):
+        m.step_finish(float("nan"))
+    assert v >= 0.0

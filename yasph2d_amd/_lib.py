@@ -79,6 +79,27 @@ def build(force=False):
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
 
 
+class SphxMultiOptions(C.Structure):
+    _fields_ = [("halo_cells", C.c_uint32), ("fixed_halo", C.c_uint32), ("rebalance_every", C.c_uint32), ("layout", C.c_uint32),
+                ("cap_records", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+COMM_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p)
+COMM_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double))
+
+
+class SphxCommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("exchange", COMM_EXCHANGE), ("allreduce", COMM_ALLREDUCE)]
+
+
+class SphxMultiInfo(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("local_tiles", C.c_uint32), ("halo_now", C.c_uint32), ("halo_max", C.c_uint32), ("peers", C.c_uint32),
+                ("n_local", C.c_uint32), ("cap_records", C.c_uint32), ("grid_layout", C.c_uint32), ("axis", C.c_int32), ("reserved", C.c_uint32),
+                ("exchanges", C.c_uint64), ("rebalances", C.c_uint64), ("transport", C.c_char * 96)]
+
+
+LAYOUT_AUTO, LAYOUT_STRIPS, LAYOUT_GRID = 0, 1, 2
+
 # every symbol include/sphx.h declares: (restype, argtypes)
 _vp, _u16p = C.c_void_p, C.c_void_p
 _f, _u32, _u64, _i = C.c_float, C.c_uint32, C.c_uint64, C.c_int
@@ -133,6 +154,23 @@ SIGNATURES = {
     "sphx_profile_reset": (_i, [_vp]),
     "sphx_profile_filter": (_i, [_vp, C.c_char_p, _u32]),
     "sphx_profile_get": (_i, [_vp, _vp, C.POINTER(_u32)]),
+    "sphx_multi_default_options": (_i, [C.POINTER(SphxMultiOptions)]),
+    "sphx_multi_create": (_i, [C.POINTER(SphxParams), C.POINTER(C.c_int), _i, C.POINTER(SphxMultiOptions), C.POINTER(_vp)]),
+    "sphx_multi_create_rank": (_i, [C.POINTER(SphxParams), _i, C.POINTER(SphxCommOps), C.c_char_p, _i, _i, C.POINTER(SphxMultiOptions), C.POINTER(_vp)]),
+    "sphx_multi_destroy": (None, [_vp]),
+    "sphx_multi_last_error": (C.c_char_p, [_vp]),
+    "sphx_multi_set_layout": (_i, [_vp, _i, _vp, _u32]),
+    "sphx_multi_set_grid_layout": (_i, [_vp, _u32, _u32, _vp, _vp]),
+    "sphx_multi_set_boundary": (_i, [_vp, _vp, _u32]),
+    "sphx_multi_upload": (_i, [_vp, _vp, _vp, _vp, _u32]),
+    "sphx_multi_clear_cached": (_i, [_vp]),
+    "sphx_multi_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
+    "sphx_multi_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
+    "sphx_multi_synchronize": (_i, [_vp]),
+    "sphx_multi_num_owned": (_u64, [_vp]),
+    "sphx_multi_download": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "sphx_multi_info": (_i, [_vp, C.POINTER(SphxMultiInfo)]),
+    "sphx_multi_tile_ctx": (_vp, [_vp, _u32]),
     # host mirror
     "sphx_world_create": (_vp, [_f, _f, _f]),
     "sphx_world_destroy": (None, [_vp]),

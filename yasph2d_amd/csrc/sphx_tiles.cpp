@@ -1,0 +1,1048 @@
+// sphx_tiles.cpp — the multi-GPU step loop INSIDE libsphx ("internally may drive 1-8 GPUs"; 8(e)).
+//
+// The reference's caller holds ONE Box<dyn Solver> and calls simulation_step(&mut world, &mut time_manager)
+// (src/sph/solver/mod.rs:12-18, src/main.rs:279); it knows nothing about tiles.  sphx_multi is that one object: it cuts the
+// domain into spatial tiles (strips along the longer side, or columns cut again across: DESIGN.md §7), owns one libsphx context
+// per tile, and runs the sub-steps of dfsph.rs:414-525 on all of them with one halo exchange per step and three scalar
+// reductions.  Two ways to hold the tiles:
+//   * sphx_multi_create        all tiles in THIS process, one host thread and one HIP stream per tile, devices given as a list
+//                              (what a Rust host gets: multi-GPU behind the unchanged Solver boundary); halo records move with
+//                              hipMemcpyPeerAsync between the tiles' buffers, ordered by HIP events — no host synchronisation;
+//   * sphx_multi_create_rank   ONE tile of a multi-process run (one process per GPU, the bench contract); the records travel as
+//                              grouped ncclSend / ncclRecv on the tile's stream (RCCL over xGMI, loaded at run time: libsphx has
+//                              no link dependency on it), the scalars through the shared-memory all-reduce of sphx_shm_*; or
+//                              through a communicator supplied by the caller (sphx_comm_ops: the tests use torch.distributed/gloo).
+// The step loop itself (ring budget of the ghost band, adaptive band, re-partitioning, extra exchanges for long solver loops) is the
+// one of yasph2d_amd/tiles.py, statement for statement — that Python driver stays as the reference implementation the tests
+// run over the CPU oracle; the HIP tiles driven from here must match it bit for bit (tests/test_gpu_multi.py).
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sphx.h"
+
+namespace {
+
+constexpr double INF = std::numeric_limits<double>::infinity();
+constexpr uint32_t HALO_RECORD = SPHX_HALO_RECORD_BYTES;
+
+struct Rect {
+    uint32_t x0, x1, y0, y1;
+    bool operator!=(const Rect& o) const { return x0 != o.x0 || x1 != o.x1 || y0 != o.y0 || y1 != o.y1; }
+};
+
+// GridProperties::position_to_mortoncellpos (neighborhood_search.rs:52-58) along one axis: same f32 operations as the device
+inline uint32_t cell_coord(float v, float grid_min, float cell_inv) {
+    const float c = (v - grid_min) * cell_inv;
+    if (!(c > 0.0f)) return 0;  // NaN -> 0 like Rust's saturating cast
+    if (c >= 65535.0f) return 65535;
+    return (uint32_t)c;
+}
+inline bool in_rect(uint32_t cx, uint32_t cy, const Rect& r, uint32_t halo = 0) {
+    return cx + halo >= r.x0 && cx < r.x1 + halo && cy + halo >= r.y0 && cy < r.y1 + halo;
+}
+inline bool rects_touch(const Rect& a, const Rect& b, uint32_t halo) {  // b grown by `halo` overlaps a (symmetric)
+    const int64_t gx0 = (int64_t)b.x0 - halo, gx1 = (int64_t)b.x1 + halo, gy0 = (int64_t)b.y0 - halo, gy1 = (int64_t)b.y1 + halo;
+    return (int64_t)a.x0 < gx1 && gx0 < (int64_t)a.x1 && (int64_t)a.y0 < gy1 && gy0 < (int64_t)a.y1;
+}
+
+// cut positions (cell indices) at particle-count quantiles; cuts[0] = 0, cuts[world] = 65536, strictly increasing
+std::vector<uint32_t> quantile_cuts(std::vector<uint32_t> coords, int world) {
+    std::sort(coords.begin(), coords.end());
+    std::vector<uint32_t> cuts(world + 1, 0);
+    for (int r = 1; r < world; ++r) cuts[r] = coords.empty() ? 0u : coords[(coords.size() * (size_t)r) / (size_t)world];
+    cuts[world] = 65536;
+    for (int r = 1; r <= world; ++r) cuts[r] = std::max(cuts[r], cuts[r - 1] + 1);
+    return cuts;
+}
+
+// Diffusive re-partition ("re-partition when max/mean load > ~1.1"): every interior cut moves towards the heavier
+// of its two tiles by half their difference expressed in cell columns, at most max_shift cells, never below two halo widths per
+// tile.  Pure function of rank-identical inputs.
+std::vector<uint32_t> rebalance_cuts(const std::vector<uint32_t>& cuts, const std::vector<double>& counts, uint32_t halo, double columns, int max_shift,
+                                     double threshold = 1.05) {
+    const int W = (int)counts.size();
+    double total = 0, mx = 0;
+    for (double c : counts) {
+        total += c;
+        mx = std::max(mx, c);
+    }
+    const double mean = total / std::max(W, 1);
+    if (W < 2 || mean <= 0 || mx <= threshold * mean) return cuts;
+    std::vector<int64_t> nw(cuts.begin(), cuts.end());
+    for (int r = 1; r < W; ++r) {
+        const int64_t d = (int64_t)std::nearbyint((counts[r] - counts[r - 1]) * 0.5 / std::max(columns, 1.0));  // round half to even, like Python
+        nw[r] = (int64_t)cuts[r] + std::max<int64_t>(-max_shift, std::min<int64_t>(max_shift, d));
+    }
+    const int64_t min_w = 2 * (int64_t)halo + 2;
+    for (int r = 1; r < W; ++r) nw[r] = std::max(nw[r], r > 1 ? nw[r - 1] + min_w : nw[r]);
+    for (int r = W - 1; r > 0; --r) nw[r] = std::min(nw[r], r < W - 1 ? nw[r + 1] - min_w : nw[r]);
+    for (int r = 1; r < W; ++r)
+        if (std::llabs(nw[r] - (int64_t)cuts[r]) > max_shift) return cuts;  // the width rule pushed a cut further than allowed: keep all
+    return std::vector<uint32_t>(nw.begin(), nw.end());
+}
+
+struct Layout {
+    // strips: nx or ny == 1; grid: nx columns cut at xcuts, each column cut again at its own ycuts[ix]; rank = ix * ny + iy
+    int axis = -1;  // >= 0: strips along this axis (cuts in xcuts)
+    int nx = 1, ny = 1;
+    std::vector<uint32_t> xcuts;
+    std::vector<std::vector<uint32_t>> ycuts;
+    int world() const { return axis >= 0 ? (int)xcuts.size() - 1 : nx * ny; }
+    std::vector<Rect> rects() const {
+        std::vector<Rect> out;
+        if (axis >= 0) {
+            for (size_t r = 0; r + 1 < xcuts.size(); ++r)
+                out.push_back(axis == 0 ? Rect{xcuts[r], xcuts[r + 1], 0u, 65536u} : Rect{0u, 65536u, xcuts[r], xcuts[r + 1]});
+        } else {
+            for (int ix = 0; ix < nx; ++ix)
+                for (int iy = 0; iy < ny; ++iy) out.push_back(Rect{xcuts[ix], xcuts[ix + 1], ycuts[ix][iy], ycuts[ix][iy + 1]});
+        }
+        return out;
+    }
+    bool rebalance(const std::vector<double>& counts, uint32_t halo, const double columns[2], int max_shift) {
+        if (axis >= 0) {
+            auto nw = rebalance_cuts(xcuts, counts, halo, columns[axis], max_shift);
+            const bool ch = nw != xcuts;
+            xcuts = nw;
+            return ch;
+        }
+        const auto before_x = xcuts;
+        const auto before_y = ycuts;
+        std::vector<double> col(nx, 0.0);
+        for (int ix = 0; ix < nx; ++ix)
+            for (int iy = 0; iy < ny; ++iy) col[ix] += counts[ix * ny + iy];
+        xcuts = rebalance_cuts(xcuts, col, halo, columns[0], max_shift);
+        for (int ix = 0; ix < nx; ++ix) {
+            std::vector<double> c(counts.begin() + ix * ny, counts.begin() + (ix + 1) * ny);
+            ycuts[ix] = rebalance_cuts(ycuts[ix], c, halo, columns[1] / nx, max_shift);  // a column holds 1/nx of the particles
+        }
+        return xcuts != before_x || ycuts != before_y;
+    }
+};
+
+// ---- communication between the tiles -------------------------------------------------------------------------------------
+struct Comm {
+    int rank = 0, world = 1;
+    virtual ~Comm() {}
+    // send[k] -> peers[k], recv[k] <- peers[k]; `bytes` of each buffer; ordered on the tile's stream (no host synchronisation)
+    virtual int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) = 0;
+    virtual int allreduce(const double* in, int n, int op, double* out) = 0;  // op 0 sum, 1 max; same bits on every rank
+    virtual const char* name() const = 0;
+};
+
+// caller-supplied function table (sphx_comm_ops): the tests run it over torch.distributed
+struct CallbackComm : Comm {
+    sphx_comm_ops ops;
+    explicit CallbackComm(const sphx_comm_ops& o) : ops(o) {
+        rank = o.rank;
+        world = o.world;
+    }
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+        if (peers.empty()) return SPHX_OK;
+        return ops.exchange(ops.user, peers.data(), (int)peers.size(), send.data(), recv.data(), bytes, (void*)st);
+    }
+    int allreduce(const double* in, int n, int op, double* out) override { return ops.allreduce(ops.user, in, n, op, out); }
+    const char* name() const override { return "caller-supplied communicator"; }
+};
+
+// One process per GPU on one node: halo records as grouped ncclSend/ncclRecv on the tile's stream (RCCL over xGMI — point-to-point
+// links, and the exchange is point-to-point with the <= 8 spatial neighbours: no ring collective anywhere), scalars through POSIX
+// shared memory (they already sit in host memory on every rank: ~1 us instead of a device round trip).
+struct RcclComm : Comm {
+    struct Uid {
+        char b[128];
+    };
+    void* lib = nullptr;
+    void* comm = nullptr;
+    sphx_shm* shm = nullptr;
+    int (*p_get_uid)(Uid*) = nullptr;
+    int (*p_init)(void**, int, Uid, int) = nullptr;
+    int (*p_destroy)(void*) = nullptr;
+    int (*p_send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*p_recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*p_gstart)() = nullptr;
+    int (*p_gend)() = nullptr;
+    const char* (*p_err)(int) = nullptr;
+    std::string err;
+
+    int open(const char* job, int rank_, int world_, int device) {
+        rank = rank_;
+        world = world_;
+        shm = sphx_shm_open(job, rank, world);
+        if (!shm) {
+            err = "sphx_shm_open failed";
+            return SPHX_ERR_HIP;
+        }
+        const char* always = std::getenv("SPHX_RCCL_ALWAYS");  // test aid: bring RCCL up even for a single rank
+        if (world == 1 && !(always && always[0] == '1')) return SPHX_OK;  // nothing to exchange
+        for (const char* n : {"librccl.so", "librccl.so.1"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            err = std::string("dlopen(librccl.so): ") + dlerror();
+            return SPHX_ERR_HIP;
+        }
+        p_get_uid = (int (*)(Uid*))dlsym(lib, "ncclGetUniqueId");
+        p_init = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
+        p_destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        p_send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclSend");
+        p_recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclRecv");
+        p_gstart = (int (*)())dlsym(lib, "ncclGroupStart");
+        p_gend = (int (*)())dlsym(lib, "ncclGroupEnd");
+        p_err = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        if (!p_get_uid || !p_init || !p_send || !p_recv || !p_gstart || !p_gend) {
+            err = "librccl.so lacks the ncclSend/ncclRecv entry points";
+            return SPHX_ERR_HIP;
+        }
+        Uid id;
+        std::memset(&id, 0, sizeof(id));
+        int rc = 0;
+        if (rank == 0) rc = p_get_uid(&id);
+        // rank 0's id reaches the others through the shared segment (16 doubles = 128 bytes, two all-reduce rounds of 8: every other
+        // rank contributes zeros; the bit patterns are sums of one value and zeros, i.e. exact — NaN payloads are avoided by
+        // sending the bytes as small integers)
+        double in[8], out[8];
+        for (int part = 0; part < 16 && !rc; ++part) {
+            for (int k = 0; k < 8; ++k) in[k] = rank == 0 ? (double)(unsigned char)id.b[part * 8 + k] : 0.0;
+            if (sphx_shm_allreduce(shm, in, 8, 0, out)) rc = -1;
+            for (int k = 0; k < 8; ++k) id.b[part * 8 + k] = (char)(unsigned char)out[k];
+        }
+        if (rc) {
+            err = "broadcast of the RCCL unique id failed";
+            return SPHX_ERR_HIP;
+        }
+        if (hipSetDevice(device) != hipSuccess) {
+            err = "hipSetDevice";
+            return SPHX_ERR_HIP;
+        }
+        rc = p_init(&comm, world, id, rank);
+        if (rc) {
+            err = std::string("ncclCommInitRank: ") + (p_err ? p_err(rc) : "error");
+            comm = nullptr;
+            return SPHX_ERR_HIP;
+        }
+        return SPHX_OK;
+    }
+    ~RcclComm() override {
+        if (comm && p_destroy) p_destroy(comm);
+        if (shm) sphx_shm_close(shm);
+    }
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+        if (peers.empty()) return SPHX_OK;
+        if (!comm) return SPHX_ERR_NOT_READY;
+        int rc = p_gstart();
+        for (size_t k = 0; k < peers.size() && !rc; ++k) {
+            rc = p_send(send[k], bytes, /*ncclUint8*/ 1, peers[k], comm, st);
+            if (!rc) rc = p_recv(recv[k], bytes, 1, peers[k], comm, st);
+        }
+        const int rc2 = p_gend();
+        if (rc || rc2) {
+            err = std::string("ncclSend/ncclRecv: ") + (p_err ? p_err(rc ? rc : rc2) : "error");
+            return SPHX_ERR_HIP;
+        }
+        return SPHX_OK;
+    }
+    int allreduce(const double* in, int n, int op, double* out) override { return sphx_shm_allreduce(shm, in, n, op, out); }
+    const char* name() const override { return "RCCL send/recv (halo records) + shared-memory all-reduce (scalars)"; }
+};
+
+// All tiles in one process: the drivers are threads; a tile copies its peers' send buffers into its own receive buffers
+// (hipMemcpyPeerAsync on its stream, behind an event the sender recorded after packing).  The host threads only meet to hand the
+// event and buffer handles over; no one waits for the GPU.
+struct LocalShared {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    bool aborted = false;
+    struct Slot {
+        std::vector<int> peers;
+        std::vector<void*> send;
+        hipEvent_t packed = nullptr;   // recorded by the owner after its pack kernels
+        hipEvent_t drained = nullptr;  // recorded by the owner after it has copied everything it receives
+        int device = 0;
+        double val[8];
+    };
+    std::vector<Slot> slot;
+    explicit LocalShared(int w) : world(w), slot(w) {}
+    bool barrier() {  // false: another tile failed
+        std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
+        const uint64_t g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g || aborted; });
+        }
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+struct LocalComm : Comm {
+    std::shared_ptr<LocalShared> sh;
+    int device;
+    LocalComm(std::shared_ptr<LocalShared> s, int r, int dev) : sh(std::move(s)), device(dev) {
+        rank = r;
+        world = sh->world;
+        sh->slot[r].device = dev;
+        hipSetDevice(dev);
+        hipEventCreateWithFlags(&sh->slot[r].packed, hipEventDisableTiming);
+        hipEventCreateWithFlags(&sh->slot[r].drained, hipEventDisableTiming);
+    }
+    ~LocalComm() override {
+        hipSetDevice(device);
+        hipEventDestroy(sh->slot[rank].packed);
+        hipEventDestroy(sh->slot[rank].drained);
+    }
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+        LocalShared::Slot& me = sh->slot[rank];
+        me.peers = peers;
+        me.send = send;
+        if (hipEventRecord(me.packed, st) != hipSuccess) return SPHX_ERR_HIP;
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;  // everybody's send buffers and `packed` events are published
+        for (size_t k = 0; k < peers.size(); ++k) {
+            LocalShared::Slot& p = sh->slot[peers[k]];
+            void* src = nullptr;
+            for (size_t j = 0; j < p.peers.size(); ++j)
+                if (p.peers[j] == rank) src = p.send[j];
+            if (!src) return SPHX_ERR_INVALID_ARGUMENT;
+            if (hipStreamWaitEvent(st, p.packed, 0) != hipSuccess) return SPHX_ERR_HIP;
+            if (hipMemcpyPeerAsync(recv[k], device, src, p.device, bytes, st) != hipSuccess) return SPHX_ERR_HIP;
+        }
+        if (hipEventRecord(me.drained, st) != hipSuccess) return SPHX_ERR_HIP;
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;  // everybody's copies are queued ...
+        // ... and nobody's next pack may overwrite a send buffer before its readers have drained it
+        for (int p : peers)
+            if (hipStreamWaitEvent(st, sh->slot[p].drained, 0) != hipSuccess) return SPHX_ERR_HIP;
+        return SPHX_OK;
+    }
+    int allreduce(const double* in, int n, int op, double* out) override {
+        for (int k = 0; k < n; ++k) sh->slot[rank].val[k] = in[k];
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;
+        for (int k = 0; k < n; ++k) {
+            double acc = sh->slot[0].val[k];
+            for (int r = 1; r < world; ++r) acc = op == 1 ? std::max(acc, sh->slot[r].val[k]) : acc + sh->slot[r].val[k];  // rank order: same bits everywhere
+            out[k] = acc;
+        }
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;
+        return SPHX_OK;
+    }
+    const char* name() const override { return "in-process tiles (peer copies ordered by HIP events)"; }
+};
+
+// ---- one tile ---------------------------------------------------------------------------------------------------------------
+struct TileDriver {
+    sphx_ctx* ctx = nullptr;
+    std::unique_ptr<Comm> comm;
+    sphx_params P;
+    sphx_multi_options O;
+    Layout layout;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint32_t halo_max = 16, halo_now = 16, min_halo = 6;
+    std::vector<int> spent;
+    uint32_t last_div_iters = 1, last_div_warm = 0;
+    uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
+    uint32_t cap = 0;
+    uint64_t exchanges = 0, rebalances = 0, steps = 0;
+    const uint32_t boundary_margin = 256;
+    double valid = INF, kvalid = INF, avalid = INF;
+    Rect rect{}, clip_rect{};
+    std::vector<int> peers;
+    std::vector<Rect> peer_rects;
+    std::vector<std::pair<void*, void*>> bufs;  // per rank: {send, recv} device buffers (allocated on first use)
+    double columns[2] = {1, 1};
+    uint64_t n_owned_local = 0, n_owned_global = 0;
+    uint32_t n_local = 0;
+    std::vector<float> boundary;
+    std::vector<uint32_t> bcx, bcy;
+    float grid_min[2], cell_inv;
+    // step in flight
+    float step_dt_prev = 0, step_vmax = 0;
+    bool in_step = false;
+
+    int fail(int rc, const std::string& what) {
+        err = what;
+        if (ctx && rc != SPHX_OK) {
+            const char* e = sphx_last_error(ctx);
+            if (e && *e) err += std::string(": ") + e;
+        }
+        return rc;
+    }
+#define TCHK(expr)                                \
+    do {                                          \
+        const int rc__ = (expr);                  \
+        if (rc__) return fail(rc__, #expr);       \
+    } while (0)
+
+    ~TileDriver() {
+        if (ctx) {
+            hipSetDevice(device);
+            sphx_synchronize(ctx);
+            sphx_set_stream(ctx, nullptr);
+            sphx_destroy(ctx);
+        }
+        for (auto& b : bufs) {
+            if (b.first) hipFree(b.first);
+            if (b.second) hipFree(b.second);
+        }
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    int init(const sphx_params& params, int dev, const sphx_multi_options& opt, std::unique_ptr<Comm> c) {
+        P = params;
+        P.device = dev;
+        O = opt;
+        device = dev;
+        comm = std::move(c);
+        halo_max = O.halo_cells ? O.halo_cells : 16;
+        min_halo = std::min<uint32_t>(6, halo_max);
+        halo_now = halo_max;
+        grid_min[0] = P.grid_min[0];
+        grid_min[1] = P.grid_min[1];
+        cell_inv = 1.0f / P.smoothing_length;
+        int rc = sphx_create(&P, &ctx);
+        if (rc) return fail(rc, sphx_last_error(nullptr));
+        if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail(SPHX_ERR_HIP, "hipStreamCreate");
+        // the tile's kernels and its communication share one stream: pack -> exchange -> unpack are ordered by the stream
+        TCHK(sphx_set_stream(ctx, stream));
+        bufs.assign(comm->world, {nullptr, nullptr});
+        return SPHX_OK;
+    }
+
+    // ---- geometry
+    int place() {
+        const auto rects = layout.rects();
+        rect = rects[comm->rank];
+        peers.clear();
+        for (int k = 0; k < comm->world; ++k)
+            if (k != comm->rank && rects_touch(rect, rects[k], halo_max)) peers.push_back(k);
+        if (peers.size() > SPHX_MAX_TILE_PEERS) return fail(SPHX_ERR_INVALID_ARGUMENT, "a tile touches more than 8 others: tiles are too small for this halo");
+        auto too_narrow = [&](const Rect& r) {
+            return (r.x0 > 0 && r.x1 < 65536 && r.x1 - r.x0 < 2 * halo_max) || (r.y0 > 0 && r.y1 < 65536 && r.y1 - r.y0 < 2 * halo_max);
+        };
+        if (too_narrow(rect)) return fail(SPHX_ERR_INVALID_ARGUMENT, "tiles must be at least two halo widths wide");
+        for (int k : peers)
+            if (too_narrow(rects[k])) return fail(SPHX_ERR_INVALID_ARGUMENT, "tiles must be at least two halo widths wide");
+        peer_rects.clear();
+        for (int k : peers) peer_rects.push_back(rects[k]);
+        return configure();
+    }
+    int configure() {
+        sphx_tile_rect own{rect.x0, rect.x1, rect.y0, rect.y1};
+        std::vector<sphx_tile_rect> pr;
+        for (const Rect& r : peer_rects) pr.push_back(sphx_tile_rect{r.x0, r.x1, r.y0, r.y1});
+        sphx_tile_rect dummy{0, 1, 0, 1};
+        TCHK(sphx_tile_configure_rect(ctx, &own, halo_now, pr.empty() ? &dummy : pr.data(), (uint32_t)pr.size()));
+        return SPHX_OK;
+    }
+    int clip_boundary() {
+        const uint32_t m = halo_max + 2 + (O.rebalance_every ? boundary_margin : 0);
+        clip_rect = rect;
+        std::vector<float> keep;
+        for (size_t i = 0; i < bcx.size(); ++i)
+            if (in_rect(bcx[i], bcy[i], rect, m)) {
+                keep.push_back(boundary[2 * i]);
+                keep.push_back(boundary[2 * i + 1]);
+            }
+        TCHK(sphx_set_boundary(ctx, keep.empty() ? nullptr : keep.data(), (uint32_t)(keep.size() / 2)));
+        return SPHX_OK;
+    }
+    int buffers(std::vector<void*>& send, std::vector<void*>& recv) {
+        const size_t bytes = (size_t)(1 + cap) * HALO_RECORD;
+        hipSetDevice(device);
+        for (int k : peers) {
+            if (!bufs[k].first) {
+                if (hipMalloc(&bufs[k].first, bytes) != hipSuccess || hipMalloc(&bufs[k].second, bytes) != hipSuccess) return fail(SPHX_ERR_HIP, "hipMalloc (halo buffers)");
+                hipMemsetAsync(bufs[k].first, 0, bytes, stream);
+                hipMemsetAsync(bufs[k].second, 0, bytes, stream);
+            }
+            send.push_back(bufs[k].first);
+            recv.push_back(bufs[k].second);
+        }
+        return SPHX_OK;
+    }
+
+    // ---- set-up: every rank is given the SAME global arrays (deterministic scene) and keeps its own cells
+    int setup(const Layout& lay, const float* pos, const float* vel, const uint32_t* ids, uint32_t n, const float* bnd, uint32_t nb) {
+        layout = lay;
+        if (layout.world() != comm->world) return fail(SPHX_ERR_INVALID_ARGUMENT, "layout and communicator disagree about the number of tiles");
+        std::vector<uint32_t> cx(n), cy(n);
+        uint32_t x0 = 0xFFFFFFFFu, x1 = 0, y0 = 0xFFFFFFFFu, y1 = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            cx[i] = cell_coord(pos[2 * i], grid_min[0], cell_inv);
+            cy[i] = cell_coord(pos[2 * i + 1], grid_min[1], cell_inv);
+            x0 = std::min(x0, cx[i]);
+            x1 = std::max(x1, cx[i]);
+            y0 = std::min(y0, cy[i]);
+            y1 = std::max(y1, cy[i]);
+        }
+        int rc = place();
+        if (rc) return rc;
+        const auto rects = layout.rects();
+        const int W = comm->world;
+        std::vector<uint32_t> mine;
+        if (O.cap_records) {
+            cap = O.cap_records;
+            for (uint32_t i = 0; i < n; ++i)
+                if (in_rect(cx[i], cy[i], rect)) mine.push_back(i);
+        } else {
+            // particles a tile has to send to one peer: estimate from the global scene, with head-room for compression waves
+            std::vector<uint64_t> cnt((size_t)W * W, 0);
+            std::vector<uint8_t> touch((size_t)W * W, 0);
+            for (int a = 0; a < W; ++a)
+                for (int b = 0; b < W; ++b) touch[(size_t)a * W + b] = a != b && rects_touch(rects[a], rects[b], halo_max);
+            for (uint32_t i = 0; i < n; ++i) {
+                int a = -1;
+                for (int r = 0; r < W; ++r)
+                    if (in_rect(cx[i], cy[i], rects[r])) {
+                        a = r;
+                        break;
+                    }
+                if (a < 0) continue;
+                if (a == comm->rank) mine.push_back(i);
+                for (int b = 0; b < W; ++b)
+                    if (touch[(size_t)a * W + b] && in_rect(cx[i], cy[i], rects[b], halo_max)) cnt[(size_t)a * W + b] += 1;
+            }
+            uint64_t near = 0;
+            for (uint64_t c : cnt) near = std::max(near, c);
+            cap = (uint32_t)std::max<uint64_t>(1024, (uint64_t)(near * 1.5) + 1024);
+        }
+        const uint64_t n_own = mine.size();
+        TCHK(sphx_reserve(ctx, (uint32_t)((uint64_t)(n_own * 1.25) + 2ull * std::max<size_t>(2, peers.size()) * cap + 4096)));
+        auto span = [](uint32_t lo, uint32_t hi, uint32_t cnt) { return cnt ? std::max<uint32_t>(1, hi - lo + 1) : 1u; };
+        columns[0] = (double)n / span(x0, x1, n);
+        columns[1] = (double)n / span(y0, y1, n);
+        n_owned_local = n_own;
+        boundary.assign(bnd, bnd + 2 * (size_t)nb);
+        bcx.resize(nb);
+        bcy.resize(nb);
+        for (uint32_t i = 0; i < nb; ++i) {
+            bcx[i] = cell_coord(bnd[2 * i], grid_min[0], cell_inv);
+            bcy[i] = cell_coord(bnd[2 * i + 1], grid_min[1], cell_inv);
+        }
+        if (nb) {
+            rc = clip_boundary();
+            if (rc) return rc;
+        }
+        std::vector<float> p(2 * n_own), v(2 * n_own, 0.0f);
+        std::vector<uint32_t> id(n_own);
+        for (uint64_t k = 0; k < n_own; ++k) {
+            const uint32_t i = mine[k];
+            p[2 * k] = pos[2 * i];
+            p[2 * k + 1] = pos[2 * i + 1];
+            if (vel) {
+                v[2 * k] = vel[2 * i];
+                v[2 * k + 1] = vel[2 * i + 1];
+            }
+            id[k] = ids ? ids[i] : i;
+        }
+        TCHK(sphx_tile_upload(ctx, p.data(), v.data(), id.data(), (uint32_t)n_own));
+        n_owned_global = n;
+        num_density_iters = 1;
+        num_divergence_iters = 0;
+        spent.clear();
+        return refresh();  // initial ghosts + the warm-up block (dfsph.rs:419-428): re-grid, densities, alpha
+    }
+
+    // ---- halo
+    uint32_t cap_now() const {
+        if (halo_now >= halo_max) return cap;
+        const uint64_t scaled = ((uint64_t)cap * (halo_now + 4) + (halo_max + 4) - 1) / (halo_max + 4);
+        return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1024, scaled));
+    }
+    int refresh() {  // halo exchange (migration + fresh ghosts) followed by the re-grid of the local set
+        std::vector<void*> send, recv;
+        int rc = buffers(send, recv);
+        if (rc) return rc;
+        const uint32_t c = cap_now();
+        const size_t bytes = (size_t)(1 + c) * HALO_RECORD;  // only the part the band in use can fill travels
+        void* dummy = nullptr;
+        TCHK(sphx_tile_pack_n(ctx, send.empty() ? &dummy : send.data(), (uint32_t)send.size(), c));
+        rc = comm->exchange(peers, send, recv, bytes, stream);
+        if (rc) return fail(rc, "halo exchange failed");
+        const void* cdummy = nullptr;
+        TCHK(sphx_tile_apply_n(ctx, recv.empty() ? &cdummy : (const void* const*)recv.data(), (uint32_t)recv.size(), c));
+        TCHK(sphx_sub_regrid(ctx, &n_local));
+        exchanges += 1;
+        const double full = comm->world == 1 ? INF : (double)halo_now;
+        valid = kvalid = full;  // rings (cells from the owned region) in which v* / kappa are exact
+        avalid = full - 1;      // ... density and alpha (one traversal after the exchange)
+        return SPHX_OK;
+    }
+    int need(double after) {  // make sure the owned region stays exact after an operation that leaves `after` valid rings
+        return after < 0 ? refresh() : SPHX_OK;
+    }
+    void adapt_halo(int used) {
+        spent.push_back(used);
+        if (spent.size() > 8) spent.erase(spent.begin());
+        const int mx = *std::max_element(spent.begin(), spent.end());
+        const uint32_t nw = (uint32_t)std::max<int>((int)min_halo, std::min<int>((int)halo_max, mx + 2));
+        if (nw != halo_now) {
+            halo_now = nw;
+            configure();
+        }
+    }
+    int rebalance() {
+        std::vector<double> counts(comm->world, 0.0);
+        for (int base = 0; base < comm->world; base += 8) {  // the shared-memory reduction carries 8 doubles per call
+            const int m = std::min(8, comm->world - base);
+            double in[8] = {0}, out[8];
+            for (int k = 0; k < m; ++k) in[k] = base + k == comm->rank ? (double)n_owned_local : 0.0;
+            TCHK(comm->allreduce(in, m, 0, out));
+            for (int k = 0; k < m; ++k) counts[base + k] = out[k];
+        }
+        if (!layout.rebalance(counts, halo_max, columns, (int)std::max<uint32_t>(1, std::min(halo_max / 4, min_halo)))) return SPHX_OK;
+        int rc = place();
+        if (rc) return rc;
+        auto far = [&](uint32_t a, uint32_t b) { return (a > b ? a - b : b - a) > boundary_margin / 2; };
+        if (!boundary.empty() && (far(rect.x0, clip_rect.x0) || far(rect.x1, clip_rect.x1) || far(rect.y0, clip_rect.y0) || far(rect.y1, clip_rect.y1))) {
+            rc = clip_boundary();
+            if (rc) return rc;
+        }
+        rebalances += 1;
+        return SPHX_OK;
+    }
+
+    // ---- one solver loop (dfsph.rs:195-247 / :346-402) with the residual all-reduced over the tiles
+    int loop(bool divergence, float dt, uint32_t* out_iters, float* out_avg, uint32_t* out_warm, uint32_t* flags) {
+        const uint32_t prev = divergence ? num_divergence_iters : num_density_iters;
+        const uint32_t fixed = divergence ? P.fixed_divergence_iterations : P.fixed_density_iterations;
+        const float tol = divergence ? P.max_divergence_error : P.max_avg_density_error;
+        const uint32_t capit = divergence ? P.max_divergence_iterations : P.max_density_iterations;
+        const float rho0 = P.fluid_density;
+        uint32_t warm = 0;
+        if (prev > 1) {  // dfsph.rs:199 / :354
+            int rc = need(std::min(valid, kvalid - 1));
+            if (rc) return rc;
+            TCHK(sphx_sub_warmstart(ctx, divergence ? 1 : 0, dt));
+            valid = std::min(valid, kvalid - 1);
+            warm = 1;
+        }
+        uint32_t iters = 0;
+        float avg = 0;
+        for (;;) {
+            int rc = need(std::min(valid - 2, avalid - 1));
+            if (rc) return rc;
+            const double kv = std::min(valid - 1, avalid);
+            double s = 0;
+            uint64_t owned = 0;
+            TCHK(sphx_sub_iteration(ctx, divergence ? 1 : 0, dt, iters == 0, &s, &owned));
+            n_owned_local = owned;
+            valid = std::min(valid - 2, avalid - 1);
+            kvalid = kv;
+            iters += 1;
+            double in[2] = {s, (double)owned}, out[2];
+            TCHK(comm->allreduce(in, 2, 0, out));
+            n_owned_global = (uint64_t)out[1];
+            avg = (float)out[0] / (float)out[1];             // dfsph.rs:221
+            if (divergence) avg = avg / rho0;                // dfsph.rs:376-377
+            if (!std::isfinite(avg)) return fail(SPHX_ERR_NONFINITE, "residual is not finite (dfsph.rs:223,378)");
+            if (fixed) {
+                if (iters >= fixed) break;
+                continue;
+            }
+            const float rel = divergence ? avg : avg / rho0;  // dfsph.rs:222
+            if (rel * dt < tol) break;                        // dfsph.rs:226 / :381
+            if (iters > capit) {                              // dfsph.rs:236 / :391
+                *flags |= divergence ? SPHX_FLAG_DIVERGENCE_ITER_CAP : SPHX_FLAG_DENSITY_ITER_CAP;
+                break;
+            }
+        }
+        if (divergence)
+            num_divergence_iters = iters;
+        else
+            num_density_iters = iters;
+        *out_iters = iters;
+        *out_avg = avg;
+        *out_warm = warm;
+        return SPHX_OK;
+    }
+
+    // ---- Solver::simulation_step, two-phase like the single context (the caller's TimeManager sits in between, dfsph.rs:478-480)
+    int step_begin(float dt_prev, float* out_vmax) {
+        if (in_step) return fail(SPHX_ERR_NOT_READY, "sphx_multi_step_begin called twice");
+        int rc = need(std::min(avalid, valid) - 1);
+        if (rc) return rc;
+        float vsq = 0;
+        TCHK(sphx_sub_nonpressure(ctx, dt_prev, &vsq));  // dfsph.rs:436-477
+        double in = vsq, out = 0;
+        TCHK(comm->allreduce(&in, 1, 1, &out));
+        const float vs = (float)out;
+        if (!std::isfinite(vs)) return fail(SPHX_ERR_NONFINITE, "max velocity is not finite (timemanager.rs:264 would panic)");
+        step_vmax = std::sqrt(vs);  // dfsph.rs:479
+        step_dt_prev = dt_prev;
+        *out_vmax = step_vmax;
+        in_step = true;
+        return SPHX_OK;
+    }
+    int step_finish(float dt, sphx_step_stats* st) {
+        if (!in_step) return fail(SPHX_ERR_NOT_READY, "sphx_multi_step_finish without sphx_multi_step_begin");
+        in_step = false;
+        sphx_step_stats s;
+        std::memset(&s, 0, sizeof(s));
+        s.dt_prev = step_dt_prev;
+        s.dt = dt;
+        s.vmax = step_vmax;
+        TCHK(sphx_sub_predict(ctx, dt));  // dfsph.rs:484-492
+        valid = std::min(avalid, valid) - 1;
+        int rc = loop(false, dt, &s.density_iterations, &s.avg_density_error, &s.warmstart_density, &s.flags);  // dfsph.rs:496
+        if (rc) return rc;
+        TCHK(sphx_sub_advect(ctx, dt));  // dfsph.rs:499-510 (ghosts move with their exact copies' v*)
+        steps += 1;
+        if (O.rebalance_every && comm->world > 1 && steps % O.rebalance_every == 0) {
+            rc = rebalance();
+            if (rc) return rc;
+        }
+        if (!O.fixed_halo && comm->world > 1)
+            // rings of the interval that ends here: divergence loop of the previous step, non-pressure pass, this density loop, and
+            // the one-ring offset of density/alpha (computed one traversal after the exchange)
+            adapt_halo((int)(last_div_warm + 2 * last_div_iters + 1 + s.warmstart_density + 2 * s.density_iterations + 1));
+        rc = refresh();  // migration + ghosts, dfsph.rs:512-518
+        if (rc) return rc;
+        rc = loop(true, dt, &s.divergence_iterations, &s.avg_divergence, &s.warmstart_divergence, &s.flags);  // dfsph.rs:521
+        if (rc) return rc;
+        last_div_iters = s.divergence_iterations;
+        last_div_warm = s.warmstart_divergence;
+        s.neighbor_entries = 0;
+        if (st) *st = s;
+        return SPHX_OK;
+    }
+};
+
+// which layout for `world` tiles over these particles: 2x2 (2 x N/2) on 4 tiles, strips along the longer side otherwise
+Layout make_layout(const sphx_multi_options& O, const sphx_params& P, int world, const float* pos, uint32_t n) {
+    const float cell_inv = 1.0f / P.smoothing_length;
+    std::vector<uint32_t> cx(n), cy(n);
+    float lo[2] = {1e30f, 1e30f}, hi[2] = {-1e30f, -1e30f};
+    for (uint32_t i = 0; i < n; ++i) {
+        cx[i] = cell_coord(pos[2 * i], P.grid_min[0], cell_inv);
+        cy[i] = cell_coord(pos[2 * i + 1], P.grid_min[1], cell_inv);
+        for (int a = 0; a < 2; ++a) {
+            lo[a] = std::min(lo[a], pos[2 * i + a]);
+            hi[a] = std::max(hi[a], pos[2 * i + a]);
+        }
+    }
+    const int axis = (hi[1] - lo[1]) > (hi[0] - lo[0]) ? 1 : 0;
+    Layout L;
+    const bool grid = O.layout == SPHX_LAYOUT_GRID || (O.layout == SPHX_LAYOUT_AUTO && world == 4);
+    if (grid && world % 2 == 0 && world >= 4) {
+        L.axis = -1;
+        L.nx = axis == 1 ? 2 : world / 2;
+        L.ny = world / L.nx;
+        L.xcuts = quantile_cuts(cx, L.nx);
+        for (int ix = 0; ix < L.nx; ++ix) {
+            std::vector<uint32_t> col;
+            for (uint32_t i = 0; i < n; ++i)
+                if (cx[i] >= L.xcuts[ix] && cx[i] < L.xcuts[ix + 1]) col.push_back(cy[i]);
+            L.ycuts.push_back(quantile_cuts(col.empty() ? cy : col, L.ny));
+        }
+    } else {
+        L.axis = axis;
+        L.xcuts = quantile_cuts(axis == 0 ? cx : cy, world);
+    }
+    return L;
+}
+
+}  // namespace
+
+// ======================================================================================================================
+// sphx_multi: N tiles in this process (worker threads), or one tile of a multi-process run
+// ======================================================================================================================
+struct sphx_multi {
+    std::vector<std::unique_ptr<TileDriver>> tiles;  // in-process: all of them; rank mode: exactly one
+    bool rank_mode = false;
+    int world = 1;
+    sphx_params P;
+    sphx_multi_options O;
+    std::string err;
+    std::shared_ptr<LocalShared> shared;
+    std::vector<float> boundary;  // host copy until the upload
+    bool have_layout = false;
+    Layout explicit_layout;
+
+    // run f(tile, index) on every tile, each on its own host thread (the tiles meet in barriers); returns the first error
+    int each(const std::function<int(TileDriver&, size_t)>& f) {
+        if (tiles.size() == 1) {
+            const int rc = f(*tiles[0], 0);
+            if (rc) err = tiles[0]->err;
+            return rc;
+        }
+        std::vector<int> rcs(tiles.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < tiles.size(); ++r)
+            th.emplace_back([&, r] {
+                rcs[r] = f(*tiles[r], r);
+                if (rcs[r] && shared) shared->abort();
+            });
+        for (auto& t : th) t.join();
+        for (size_t r = 0; r < tiles.size(); ++r)
+            if (rcs[r] && rcs[r] != SPHX_ERR_NOT_READY) {
+                err = "tile " + std::to_string(r) + ": " + tiles[r]->err;
+                return rcs[r];
+            }
+        for (size_t r = 0; r < tiles.size(); ++r)
+            if (rcs[r]) {
+                err = "tile " + std::to_string(r) + ": " + tiles[r]->err;
+                return rcs[r];
+            }
+        return SPHX_OK;
+    }
+};
+
+static std::string g_multi_error;
+
+extern "C" {
+
+int sphx_multi_default_options(sphx_multi_options* o) {
+    if (!o) return SPHX_ERR_INVALID_ARGUMENT;
+    std::memset(o, 0, sizeof(*o));
+    o->halo_cells = 16;
+    o->rebalance_every = 16;
+    o->layout = SPHX_LAYOUT_AUTO;
+    return SPHX_OK;
+}
+
+const char* sphx_multi_last_error(const sphx_multi* m) { return m ? m->err.c_str() : g_multi_error.c_str(); }
+
+int sphx_multi_create(const sphx_params* params, const int* devices, int n_devices, const sphx_multi_options* opt, sphx_multi** out) {
+    if (!params || !devices || n_devices < 1 || n_devices > 64 || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<sphx_multi> m(new sphx_multi());
+    m->P = *params;
+    if (opt)
+        m->O = *opt;
+    else
+        sphx_multi_default_options(&m->O);
+    m->world = n_devices;
+    m->shared = std::make_shared<LocalShared>(n_devices);
+    for (int r = 0; r < n_devices; ++r) {
+        std::unique_ptr<TileDriver> t(new TileDriver());
+        const int rc = t->init(*params, devices[r], m->O, std::unique_ptr<Comm>(new LocalComm(m->shared, r, devices[r])));
+        if (rc) {
+            g_multi_error = "tile " + std::to_string(r) + ": " + t->err;
+            return rc;
+        }
+        m->tiles.push_back(std::move(t));
+    }
+    *out = m.release();
+    return SPHX_OK;
+}
+
+int sphx_multi_create_rank(const sphx_params* params, int device, const sphx_comm_ops* comm, const char* job, int rank, int world,
+                           const sphx_multi_options* opt, sphx_multi** out) {
+    if (!params || !out || world < 1 || rank < 0 || rank >= world) return SPHX_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<sphx_multi> m(new sphx_multi());
+    m->P = *params;
+    if (opt)
+        m->O = *opt;
+    else
+        sphx_multi_default_options(&m->O);
+    m->world = world;
+    m->rank_mode = true;
+    std::unique_ptr<Comm> c;
+    if (comm) {
+        if (!comm->exchange || !comm->allreduce || comm->rank != rank || comm->world != world) return SPHX_ERR_INVALID_ARGUMENT;
+        c.reset(new CallbackComm(*comm));
+    } else {
+        if (!job) return SPHX_ERR_INVALID_ARGUMENT;
+        std::unique_ptr<RcclComm> rc(new RcclComm());
+        const int e = rc->open(job, rank, world, device);
+        if (e) {
+            g_multi_error = rc->err;
+            return e;
+        }
+        c = std::move(rc);
+    }
+    std::unique_ptr<TileDriver> t(new TileDriver());
+    const int rc = t->init(*params, device, m->O, std::move(c));
+    if (rc) {
+        g_multi_error = t->err;
+        return rc;
+    }
+    m->tiles.push_back(std::move(t));
+    *out = m.release();
+    return SPHX_OK;
+}
+
+void sphx_multi_destroy(sphx_multi* m) { delete m; }
+
+int sphx_multi_set_layout(sphx_multi* m, int axis, const uint32_t* cuts, uint32_t n_cuts) {
+    if (!m || (axis != 0 && axis != 1) || !cuts || (int)n_cuts != m->world + 1) return SPHX_ERR_INVALID_ARGUMENT;
+    m->explicit_layout = Layout();
+    m->explicit_layout.axis = axis;
+    m->explicit_layout.xcuts.assign(cuts, cuts + n_cuts);
+    m->have_layout = true;
+    return SPHX_OK;
+}
+int sphx_multi_set_grid_layout(sphx_multi* m, uint32_t nx, uint32_t ny, const uint32_t* xcuts, const uint32_t* ycuts) {
+    if (!m || !xcuts || !ycuts || (int)(nx * ny) != m->world) return SPHX_ERR_INVALID_ARGUMENT;
+    Layout L;
+    L.axis = -1;
+    L.nx = (int)nx;
+    L.ny = (int)ny;
+    L.xcuts.assign(xcuts, xcuts + nx + 1);
+    for (uint32_t ix = 0; ix < nx; ++ix) L.ycuts.emplace_back(ycuts + (size_t)ix * (ny + 1), ycuts + (size_t)(ix + 1) * (ny + 1));
+    m->explicit_layout = L;
+    m->have_layout = true;
+    return SPHX_OK;
+}
+
+int sphx_multi_set_boundary(sphx_multi* m, const float* xy, uint32_t n) {
+    if (!m || (n && !xy)) return SPHX_ERR_INVALID_ARGUMENT;
+    m->boundary.assign(xy, xy + 2 * (size_t)n);
+    return SPHX_OK;
+}
+
+int sphx_multi_upload(sphx_multi* m, const float* pos_xy, const float* vel_xy, const uint32_t* ids, uint32_t n) {
+    if (!m || (n && !pos_xy)) return SPHX_ERR_INVALID_ARGUMENT;
+    const Layout L = m->have_layout ? m->explicit_layout : make_layout(m->O, m->P, m->world, pos_xy, n);
+    return m->each([&](TileDriver& t, size_t) {
+        return t.setup(L, pos_xy, vel_xy, ids, n, m->boundary.empty() ? nullptr : m->boundary.data(), (uint32_t)(m->boundary.size() / 2));
+    });
+}
+
+int sphx_multi_step_begin(sphx_multi* m, float dt_prev, float* out_vmax) {
+    if (!m || !out_vmax) return SPHX_ERR_INVALID_ARGUMENT;
+    std::vector<float> v(m->tiles.size(), 0.0f);
+    const int rc = m->each([&](TileDriver& t, size_t k) { return t.step_begin(dt_prev, &v[k]); });
+    if (rc) return rc;
+    *out_vmax = v[0];  // identical on every tile (all-reduced)
+    return SPHX_OK;
+}
+
+int sphx_multi_step_finish(sphx_multi* m, float dt, sphx_step_stats* out) {
+    if (!m) return SPHX_ERR_INVALID_ARGUMENT;
+    if (!(dt > 0) || !std::isfinite(dt)) {
+        for (auto& t : m->tiles) t->in_step = false;
+        m->err = "dt must be positive and finite";
+        return SPHX_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<sphx_step_stats> st(m->tiles.size());
+    const int rc = m->each([&](TileDriver& t, size_t k) { return t.step_finish(dt, &st[k]); });
+    if (rc) return rc;
+    if (out) *out = st[0];  // iteration counts, residuals and dt are identical on every tile
+    return SPHX_OK;
+}
+
+// Solver::clear_cached_data (dfsph.rs:406-412) on every tile
+int sphx_multi_clear_cached(sphx_multi* m) {
+    if (!m) return SPHX_ERR_INVALID_ARGUMENT;
+    for (auto& t : m->tiles) {
+        const int rc = sphx_clear_cached(t->ctx);
+        if (rc) {
+            m->err = sphx_last_error(t->ctx);
+            return rc;
+        }
+        t->num_density_iters = 0;
+        t->num_divergence_iters = 0;
+    }
+    return SPHX_OK;
+}
+
+int sphx_multi_synchronize(sphx_multi* m) {
+    if (!m) return SPHX_ERR_INVALID_ARGUMENT;
+    for (auto& t : m->tiles) {
+        const int rc = sphx_synchronize(t->ctx);
+        if (rc) return rc;
+    }
+    return SPHX_OK;
+}
+
+// number of particles the local tiles own (rank mode: this rank's; in-process: all)
+uint64_t sphx_multi_num_owned(const sphx_multi* m) {
+    uint64_t n = 0;
+    if (m)
+        for (auto& t : m->tiles) n += t->n_owned_local;
+    return n;
+}
+
+// Owned particles of the local tiles, concatenated tile after tile; any pointer may be NULL.  *inout_n: capacity in, count out.
+int sphx_multi_download(sphx_multi* m, float* pos_xy, float* vel_xy, float* density, uint32_t* ids, uint64_t* inout_n) {
+    if (!m || !inout_n) return SPHX_ERR_INVALID_ARGUMENT;
+    uint64_t done = 0;
+    for (auto& t : m->tiles) {
+        const uint32_t nl = sphx_num_particles(t->ctx);
+        std::vector<float> p(2 * (size_t)nl), v(2 * (size_t)nl), d(nl);
+        std::vector<uint32_t> id(nl);
+        const int rc = sphx_download(t->ctx, p.data(), v.data(), d.data(), id.data());
+        if (rc) {
+            m->err = sphx_last_error(t->ctx);
+            return rc;
+        }
+        for (uint32_t i = 0; i < nl; ++i) {
+            if (!(id[i] >> 31)) continue;  // a ghost
+            if (done < *inout_n) {
+                if (pos_xy) {
+                    pos_xy[2 * done] = p[2 * (size_t)i];
+                    pos_xy[2 * done + 1] = p[2 * (size_t)i + 1];
+                }
+                if (vel_xy) {
+                    vel_xy[2 * done] = v[2 * (size_t)i];
+                    vel_xy[2 * done + 1] = v[2 * (size_t)i + 1];
+                }
+                if (density) density[done] = d[i];
+                if (ids) ids[done] = id[i] & 0x7FFFFFFFu;
+            }
+            done += 1;
+        }
+    }
+    const bool fits = done <= *inout_n;
+    *inout_n = done;
+    if (!fits) {
+        m->err = "sphx_multi_download: capacity too small";
+        return SPHX_ERR_CAPACITY;
+    }
+    return SPHX_OK;
+}
+
+int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out) {
+    if (!m || !out) return SPHX_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    const TileDriver& t = *m->tiles[0];
+    out->world = (uint32_t)m->world;
+    out->local_tiles = (uint32_t)m->tiles.size();
+    out->halo_now = t.halo_now;
+    out->halo_max = t.halo_max;
+    out->peers = (uint32_t)t.peers.size();
+    out->exchanges = t.exchanges;
+    out->rebalances = t.rebalances;
+    out->n_local = t.n_local;
+    out->cap_records = t.cap;
+    out->grid_layout = t.layout.axis < 0;
+    out->axis = t.layout.axis;
+    std::snprintf(out->transport, sizeof(out->transport), "%s", t.comm->name());
+    return SPHX_OK;
+}
+
+sphx_ctx* sphx_multi_tile_ctx(sphx_multi* m, uint32_t local_tile) { return (m && local_tile < m->tiles.size()) ? m->tiles[local_tile]->ctx : nullptr; }
+
+}  // extern "C"
