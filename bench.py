@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--tiles", default="auto", choices=["auto", "strips", "grid"],
                     help="multi-GPU layout: strips along the longer side, or a 2 x N/2 grid (auto: 2x2 on 4 GPUs, strips otherwise; SURVEY 8(e))")
     ap.add_argument("--rebalance-every", type=int, default=16, help="steps between re-partitions of the tile cuts (0 = never)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "torch"],
+                    help="halo records: libsphx's own grouped ncclSend/ncclRecv (rccl; auto with --backend nccl) or torch.distributed "
+                         "through the sphx_comm_ops table (torch; always with gloo)")
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
@@ -208,11 +211,11 @@ def main():
         params.max_divergence_error = float(np.float32(params.max_divergence_error) * np.float32(args.tolerance_scale))
     if args.lists_32bit:
         params.list_span_limit = y.LISTS_32BIT
-    ctx = y.SphxContext(params)
-
     if args.solver == "wcsph" and (world > 1 or args.force_tiles):
         raise SystemExit("--solver wcsph runs on one GPU")
+    multi = None
     if world == 1 and not args.force_tiles:
+        ctx = y.SphxContext(params)
         ctx.set_boundary(boundary)
         ctx.upload(pos)
         n = n_global
@@ -225,37 +228,43 @@ def main():
             dt_ns = timer.update_simulation_step(diam, vmax)
             return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
 
-        tiled = None
     else:
-        from yasph2d_amd.tiles import GpuTileBackend, GridLayout, ShmComm, StripLayout, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+        # The tile step loop runs INSIDE libsphx (sphx_multi, csrc/sphx_tiles.cpp): this process holds one tile.  Transport of the halo
+        # records: the library's own grouped ncclSend/ncclRecv (RCCL over xGMI) with shared-memory scalars, or — --comm torch, and
+        # always over gloo — torch.distributed through the sphx_comm_ops function table.
+        from yasph2d_amd import _lib as ylib
+        from yasph2d_amd.multi import MultiSolver, TorchCommOps
 
-        # cut at particle-count quantiles (equal particles per GPU): strips across the longer side of the fluid, or columns cut again
-        ext = pos.max(0) - pos.min(0)
-        axis = int(ext[1] > ext[0])
-        grid = args.tiles == "grid" or (args.tiles == "auto" and world == 4)
-        if grid and world % 2 == 0 and world >= 4:
-            nx, ny = (2, world // 2) if axis == 1 else (world // 2, 2)
-            layout = GridLayout.quantile(pos, nx, ny)
-            layout_name = f"{nx}x{ny} tiles (columns cut at particle-count quantiles, each column cut again across)"
+        lay = {"auto": ylib.LAYOUT_AUTO, "strips": ylib.LAYOUT_STRIPS, "grid": ylib.LAYOUT_GRID}[args.tiles]
+        kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay)
+        job = "bench" + os.environ.get("MASTER_PORT", "0")
+        if dist is None:
+            multi = MultiSolver(params, devices=[dev_index], **kw)  # --force-tiles: one tile, the tile code path
         else:
-            layout = StripLayout(axis, quantile_cuts(cell_coord(pos, axis), world))
-            layout_name = f"{world} spatial strips along {'xy'[axis]} cut at particle-count quantiles"
-        if dist is not None:
-            if args.scalar_comm == "shm":
-                comm = ShmComm(dist, torch.device("cuda", dev_index), "bench" + os.environ.get("MASTER_PORT", "0"))
-            else:
-                comm = TorchComm(dist, torch.device("cuda", dev_index))
-        else:
-            from yasph2d_amd.tiles import ThreadComm
-
-            comm = ThreadComm(ThreadComm.Shared(1), 0)
-        tiled = TiledDFSPH(GpuTileBackend(ctx, torch.device("cuda", dev_index)), comm, layout, halo=args.halo,
-                           rebalance_every=args.rebalance_every, adaptive_halo=not args.fixed_halo)
-        tiled.setup(pos, None, None, boundary)
+            use_builtin = args.comm == "rccl" or (args.comm == "auto" and args.backend == "nccl")
+            if use_builtin:
+                try:
+                    multi = MultiSolver.rank(params, dev_index, rank, world, comm=None, job=job, **kw)
+                    ok = 1.0
+                except y.SphxError as e:
+                    sys.stderr.write(f"bench.py: rank {rank}: built-in RCCL transport failed ({e}); falling back to torch.distributed\n")
+                    ok = 0.0
+                t = torch.tensor([ok], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)  # all ranks take the same decision
+                if float(t.item()) < 1.0:
+                    if multi is not None:
+                        multi.close()
+                    multi, use_builtin = None, False
+            if not use_builtin:
+                comm = TorchCommOps(dist, torch.device("cuda", dev_index), shm_name=job + "t" if args.scalar_comm == "shm" else None)
+                multi = MultiSolver.rank(params, dev_index, rank, world, comm=comm, **kw)
+        multi.set_boundary(boundary)
+        multi.upload(pos)
+        ctx = multi.tile_context(0)
         n = n_global // world
 
         def one_step():
-            st = tiled.step(timer)
+            st = multi.step(timer, diam)
             st["neighbor_entries"] = 0
             return st
 
@@ -309,7 +318,8 @@ def main():
     Iv = float(np.mean([s["divergence_iterations"] for s in stats]))
     Wd = float(np.mean([s["warmstart_density"] for s in stats]))
     Wv = float(np.mean([s["warmstart_divergence"] for s in stats]))
-    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n if tiled is None else None
+    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n if multi is None else None
+    minfo = multi.info() if multi is not None else None
 
     roof = None
     if live is not None and live["launches"]:
@@ -371,15 +381,16 @@ def main():
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "particles_total": n_global,
-                "parallelism": "single GPU" if tiled is None else
-                f"{layout_name}, ghost halo {tiled.halo_now} of <= {args.halo} cells (follows the ring budget), per step: 1 halo "
-                f"exchange (send/recv with {len(tiled.peers)} neighbours over {args.backend}) + 3 scalar all-reduces ({args.scalar_comm if dist is not None else 'local'}); {tiled.exchanges} exchanges and "
-                f"{tiled.rebalances} re-partitions in total",
+                "parallelism": "single GPU" if multi is None else
+                f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
+                f"particle-count quantiles), step loop inside libsphx (sphx_multi), ghost halo {minfo['halo_now']} of <= {args.halo} cells (follows "
+                f"the ring budget), per step: 1 halo exchange with {minfo['peers']} neighbours + 3 scalar all-reduces; transport: "
+                f"{minfo['transport']}; {minfo['exchanges']} exchanges and {minfo['rebalances']} re-partitions in total",
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
                 "max_density_iterations_seen": int(max(s["density_iterations"] for s in stats)),
                 "max_divergence_iterations_seen": int(max(s["divergence_iterations"] for s in stats)),
                 "solver_loop": "host-run (SPHX_HOST_LOOP=1)" if os.environ.get("SPHX_HOST_LOOP") == "1" else
-                "device-run (residual test on the device, iterations queued ahead)" if tiled is None else "host-run with an all-reduce per iteration",
+                "device-run (residual test on the device, iterations queued ahead)" if multi is None else "host-run with an all-reduce per iteration",
             },
             "step_model": {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
                            "list_format": "32-bit" if args.lists_32bit else "16-bit offsets (32-bit fallback per wave)",

@@ -210,6 +210,7 @@ typedef struct sphx_tile_rect { uint32_t x0, x1, y0, y1; } sphx_tile_rect; /* ce
 int sphx_tile_configure_rect(sphx_ctx* ctx, const sphx_tile_rect* own, uint32_t halo_cells, const sphx_tile_rect* peers, uint32_t n_peers);
 int sphx_tile_pack_n(sphx_ctx* ctx, void* const* d_send, uint32_t n_send, uint32_t cap_records);         /* n_send == n_peers */
 int sphx_tile_apply_n(sphx_ctx* ctx, const void* const* d_recv, uint32_t n_recv, uint32_t cap_records);  /* entries may be NULL */
+int sphx_tile_advect_pack_n(sphx_ctx* ctx, float dt, void* const* d_send, uint32_t n_send, uint32_t cap_records); /* sphx_sub_advect + sphx_tile_pack_n in one pass */
 int sphx_tile_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, const uint32_t* ids, uint32_t n); /* owned particles, global ids < 2^31 */
 #define SPHX_HALO_RECORD_BYTES 32 /* {float4 pos+vel, u32 id, f32 kappa, f32 stiffness, u32 pad}; record 0 = header (count in .id) */
 int sphx_tile_pack(sphx_ctx* ctx, void* d_send_left, void* d_send_right, uint32_t cap_records);              /* DEVICE buffers, (1+cap)*32 B */

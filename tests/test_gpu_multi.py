@@ -166,7 +166,7 @@ def test_errors_are_reported_not_thrown():
         m.set_strips(0, [0, 10, 20, 65536])  # three tiles for a two-tile solver
     with pytest.raises(y.SphxError):
         m.step_finish(0.001)  # no step open
-    m.set_strips(1, [0, 5060, 5070, 65536][:3])
+    m.set_strips(1, [0, 5060, 65536])
     m.upload(pos)
     with pytest.raises(y.SphxError):
         m.step_finish(0.001)

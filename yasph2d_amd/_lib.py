@@ -146,6 +146,7 @@ SIGNATURES = {
     "sphx_tile_configure_rect": (_i, [_vp, _vp, _u32, _vp, _u32]),
     "sphx_tile_pack_n": (_i, [_vp, _vp, _u32, _u32]),
     "sphx_tile_apply_n": (_i, [_vp, _vp, _u32, _u32]),
+    "sphx_tile_advect_pack_n": (_i, [_vp, _f, _vp, _u32, _u32]),
     "sphx_view_request": (_i, [_vp, _u32, C.POINTER(_u32)]),
     "sphx_view_fetch": (_i, [_vp, _i, C.POINTER(C.POINTER(_f)), C.POINTER(_u32)]),
     "sphx_synchronize": (_i, [_vp]),

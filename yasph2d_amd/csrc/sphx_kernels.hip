@@ -646,11 +646,20 @@ __device__ __forceinline__ uint32_t tile_send_mask(const Consts& K, const TilePe
     for (uint32_t k = 0; k < P.n; ++k) m |= rect_has(P.rect[k], cx, cy, halo) ? (1u << k) : 0u;
     return m;
 }
+// dt > 0: the advection x += v* dt (dfsph.rs:499-510) is applied on the fly — k_tile_pack then also stores the advected record, so
+// the tile step needs no separate advection pass in front of the exchange
+__device__ __forceinline__ float4 tile_advected(float4 pv, float dt) {
+    if (dt > 0.0f) {
+        pv.x = pv.x + pv.z * dt;
+        pv.y = pv.y + pv.w * dt;
+    }
+    return pv;
+}
 __global__ __launch_bounds__(256) void k_tile_count(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
-                                                     uint32_t halo, TilePeers P, uint32_t* __restrict__ blk) {
+                                                     uint32_t halo, TilePeers P, uint32_t* __restrict__ blk, float dt) {
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t m = i < n ? tile_send_mask(K, P, halo, PV[i], pid[i]) : 0u;
+    const uint32_t m = i < n ? tile_send_mask(K, P, halo, tile_advected(PV[i], dt), pid[i]) : 0u;
     for (uint32_t k = 0; k < P.n; ++k) {
         const uint32_t c = (uint32_t)__popcll(__ballot((m >> k) & 1u));
         if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6][k] = c;
@@ -696,16 +705,20 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ bl
 // stays as a ghost: the new owner receives the very same record in this exchange but cannot send it back before the next one.
 __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
-                                                    uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap) {
+                                                    uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt) {
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t id = 0, m = 0;
     if (i < n) {
-        pv = PV[i];
+        pv = tile_advected(PV[i], dt);
         id = pid[i];
         m = tile_send_mask(K, P, halo, pv, id);
+        if (dt > 0.0f) {  // fused advection: the record moves on
+            PV[i] = pv;
+            posA[i] = make_float2(pv.x, pv.y);
+        }
     }
     unsigned long long bal[MAX_TILE_PEERS];
 #pragma unroll

@@ -387,6 +387,7 @@ struct TileDriver {
     // step in flight
     float step_dt_prev = 0, step_vmax = 0;
     bool in_step = false;
+    float pending_advect_dt = 0.0f;
 
     int fail(int rc, const std::string& what) {
         err = what;
@@ -585,7 +586,12 @@ struct TileDriver {
         const uint32_t c = cap_now();
         const size_t bytes = (size_t)(1 + c) * HALO_RECORD;  // only the part the band in use can fill travels
         void* dummy = nullptr;
-        TCHK(sphx_tile_pack_n(ctx, send.empty() ? &dummy : send.data(), (uint32_t)send.size(), c));
+        if (pending_advect_dt > 0.0f) {  // the advection of dfsph.rs:499-510 rides on the packing pass
+            TCHK(sphx_tile_advect_pack_n(ctx, pending_advect_dt, send.empty() ? &dummy : send.data(), (uint32_t)send.size(), c));
+            pending_advect_dt = 0.0f;
+        } else {
+            TCHK(sphx_tile_pack_n(ctx, send.empty() ? &dummy : send.data(), (uint32_t)send.size(), c));
+        }
         rc = comm->exchange(peers, send, recv, bytes, stream);
         if (rc) return fail(rc, "halo exchange failed");
         const void* cdummy = nullptr;
@@ -715,7 +721,7 @@ struct TileDriver {
         valid = std::min(avalid, valid) - 1;
         int rc = loop(false, dt, &s.density_iterations, &s.avg_density_error, &s.warmstart_density, &s.flags);  // dfsph.rs:496
         if (rc) return rc;
-        TCHK(sphx_sub_advect(ctx, dt));  // dfsph.rs:499-510 (ghosts move with their exact copies' v*)
+        pending_advect_dt = dt;  // dfsph.rs:499-510 (ghosts move with their exact copies' v*): applied by the refresh() below
         steps += 1;
         if (O.rebalance_every && comm->world > 1 && steps % O.rebalance_every == 0) {
             rc = rebalance();
@@ -794,6 +800,11 @@ struct sphx_multi {
             const int rc = f(*tiles[0], 0);
             if (rc) err = tiles[0]->err;
             return rc;
+        }
+        if (shared) {  // a failure of the previous call released the tiles from their barriers: arm them again
+            std::lock_guard<std::mutex> lk(shared->mu);
+            shared->aborted = false;
+            shared->arrived = 0;
         }
         std::vector<int> rcs(tiles.size(), 0);
         std::vector<std::thread> th;
