@@ -25,20 +25,35 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): the practical ceiling of a streaming kernel
 
 
-def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False):
-    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the 16-bit list format
-    of this build — every list-consuming traversal moves 2*kbar + 4.125 (entries, count word, the wave's base pair / 64) instead of
-    4*kbar + 8."""
+def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5):
+    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 16-bit
+    list format of this build — every list-consuming traversal moves the count word (4), 2*kbar of entries and 4*rbar of out-of-window
+    table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists."""
     if compressed:
-        return 236.5 + 8 * kbar + Id * (76.25 + 4 * kbar) + Iv * (72.25 + 4 * kbar) + (Wd + Wv) * (40.125 + 2 * kbar)
+        save = (8 + 4 * kbar) - (4 + 2 * kbar + 4 * rbar + 4.0 / 256)  # per traversal
+        return 252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)
     return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
-    """The oracle's OpenMP build (the reference's Rayon loops restated; 'port') timed on this host's cores."""
+    """The oracle's OpenMP build (the reference's Rayon loops restated; 'port') timed on this host's cores, threads pinned
+    (OMP_PROC_BIND=close, OMP_PLACES=cores: without pinning the figure swung 1.9-3.5 M particle-steps/s between runs in round 1)."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle.oracle import Oracle, lib
 
     L = lib(omp=True)
@@ -60,6 +75,8 @@ def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
         "unit": "particle-steps/s",
         "cores": cores,
         "kind": "port",
+        "cpu": cpu_model(),
+        "threads": "OpenMP, OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
         "sample": f"{steps} DFSPH steps of the same {len(pos)}-particle dam-break after 1 warm-up step, "
                   f"C++/OpenMP restatement of yasph2d's Rayon path (not the Rust binary), {el:.1f} s",
     }
@@ -324,14 +341,16 @@ def main():
     roof = None
     if live is not None and live["launches"]:
         name, rec = dominant, live
-        avg_ms = rec["total_ms"] / rec["launches"]
+        ev_ms = ctx.profile_event_overhead()  # what an EMPTY hipEvent bracket measures on this stream, same process
+        avg_raw = rec["total_ms"] / rec["launches"]
+        avg_ms = max(avg_raw - ev_ms, 1e-6)
         ach = rec["bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
         # HBM traffic of that kernel from the PMC counters: cannot be collected from inside the process; taken from the committed
         # rocprofv3 passes of this same command (profiles/) when the workload matches, else null.
         traffic, traffic_src = None, None
         import glob
 
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_traffic_*.json"))):
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_traffic_*.json"))):
             try:
                 tj = json.load(open(tf))
                 if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
@@ -348,17 +367,23 @@ def main():
         prof = ctx.profile_get()
         roof = {
             "bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "launches": rec["launches"],
+            "frac_of_achievable_6300": ach / HBM_ACHIEVABLE_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "avg_launch_ms_with_event_bracket": avg_raw,
+            "event_bracket_overhead_ms": ev_ms, "launches": rec["launches"],
             "algorithmic_bytes_per_launch": rec["bytes"] / rec["launches"],
-            "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream",
-            "per_kernel_ms_per_step": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
+            "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream, minus the "
+                        "elapsed time of an empty event bracket measured in the same process",
+            "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
+            "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (each adds the overhead above and keeps "
+                    "kernels from overlapping their neighbours' tails): its sum exceeds ms_per_step; information only",
         }
 
     if rank == 0:
         value = n_global * args.steps / elapsed
         kb = kbar if kbar is not None else 8.0  # tiles do not report k; 8.0 = lattice value
+        rb = float(np.mean([s.get("remote_entries", 0) for s in stats])) / n if multi is None else 0.5
         bstep_ref = bytes_per_particle_step(kb, Id, Iv, Wd, Wv)
-        bstep = bytes_per_particle_step(kb, Id, Iv, Wd, Wv, compressed=not args.lists_32bit)
+        bstep = bytes_per_particle_step(kb, Id, Iv, Wd, Wv, compressed=not args.lists_32bit, rbar=rb)
         out = {
             "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break" if args.solver == "dfsph" else "particle-steps/sec, 2D WCSPH dam-break",
             "value": value,
@@ -393,9 +418,13 @@ def main():
                 "device-run (residual test on the device, iterations queued ahead)" if multi is None else "host-run with an all-reduce per iteration",
             },
             "step_model": {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
-                           "list_format": "32-bit" if args.lists_32bit else "16-bit offsets (32-bit fallback per wave)",
+                           "list_format": "32-bit" if args.lists_32bit else "workgroup-local 16-bit slots (32-bit fallback per wavefront)",
+                           "out_of_window_entries_per_particle": rb,
                            "achieved_GBs_whole_step_per_gpu": bstep * n * args.steps / elapsed / 1e9,
-                           "frac_of_hbm_peak_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+                           "frac_of_hbm_peak_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_achievable_6300_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_ACHIEVABLE_GBS,
+                           "note": "at 1 M particles the working set (~170 MB) sits inside the 256 MB Infinity Cache: the HBM roofline is "
+                                   "a soft bound there; 16 M (--particles 16000000) is the size where it binds"},
         }
         if roof:
             out["roofline"] = roof

@@ -96,7 +96,8 @@ typedef struct sphx_step_stats {
     float dt;                          /* dt of prediction/solve/advect (dfsph.rs:478-480) */
     float vmax;                        /* sqrt(max |v + a*dt_prev|^2) handed to TimeManager (dfsph.rs:474-479) */
     uint32_t flags;                    /* SPHX_FLAG_* */
-    uint32_t reserved;
+    uint32_t remote_entries;           /* of neighbor_entries: entries outside their workgroup's record window (they go through the
+                                          workgroup's out-of-window table; byte accounting of the list layout) */
     uint64_t neighbor_entries;         /* sum of count_total over particles (length of the neighbour list buffer) */
 } sphx_step_stats;
 
@@ -281,6 +282,10 @@ uint64_t sphx_multi_num_owned(const sphx_multi* m);
 int sphx_multi_download(sphx_multi* m, float* pos_xy, float* vel_xy, float* density, uint32_t* ids, uint64_t* inout_n);
 int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out);
 sphx_ctx* sphx_multi_tile_ctx(sphx_multi* m, uint32_t local_tile); /* inspection (neighbours, cells, profiling) */
+/* Solver::simulation_step(&mut world, &mut time_manager) (solver/mod.rs:17) in ONE call: phase A, the TimeManager mirror
+ * (simulation_step() dfsph.rs:433, update_simulation_step dfsph.rs:478-480), phase B */
+struct sphx_timer;
+int sphx_multi_simulation_step(sphx_multi* m, struct sphx_timer* timer, float particle_diameter, sphx_step_stats* out_stats);
 
 /* ---- single-node scalar reductions through POSIX shared memory ---------------------------------------------------------------
  * The three per-step scalars of the tile driver (vmax, two residual sums) already sit in host memory (pinned mailbox) on every
@@ -310,6 +315,8 @@ typedef struct sphx_kernel_time {
     double algorithmic_bytes; /* sum over launches of the algorithmic byte count of DESIGN.md */
 } sphx_kernel_time;
 int sphx_profile_get(sphx_ctx* ctx, sphx_kernel_time* out, uint32_t* inout_n);
+/* what the hipEvent bracket itself adds to a measured launch: mean elapsed time between the two events of an EMPTY bracket */
+int sphx_profile_event_overhead(sphx_ctx* ctx, double* out_ms);
 
 /* ======================================================================================================================
  * Host-side mirror of the reference's caller-side types (scene helpers, TimeManager, Solver object).  These exist so the

@@ -9,6 +9,6 @@ for v in base "$@"; do
 import json,sys
 for l in open(sys.argv[1]):
     if l.startswith('{'):
-        d=json.loads(l); print(sys.argv[2], round(d['value']/1e9,3), round(d['ms_per_step'],4), {k[:14]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step'].items()})
+        d=json.loads(l); print(sys.argv[2], round(d['value']/1e9,3), round(d['ms_per_step'],4), {k[:14]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step_event_inflated'].items()})
 PY
 done

@@ -12,7 +12,7 @@ for v in base "$@"; do
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
-    print(sys.argv[2], sys.argv[3], 'G=%.3f'%(d['value']/1e9), 'ms=%.4f'%d['ms_per_step'], {k.replace('correct_velocity_with_','CO_').replace('compute_','CE_')[:18]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step'].items()})
+    print(sys.argv[2], sys.argv[3], 'G=%.3f'%(d['value']/1e9), 'ms=%.4f'%d['ms_per_step'], {k.replace('correct_velocity_with_','CO_').replace('compute_','CE_')[:18]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step_event_inflated'].items()})
 except Exception as e: print(sys.argv[2], 'FAILED', e)
 PY
   done

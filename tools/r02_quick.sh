@@ -10,7 +10,7 @@ import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1]); c=d['config']
     print(sys.argv[2], 'G=%.3f'%(d['value']/1e9), 'ms=%.4f'%d['ms_per_step'], 'Id=%.2f Iv=%.2f k=%.2f'%(c['mean_density_iterations'],c['mean_divergence_iterations'],c['mean_neighbors'] or 0))
-    print('   ', {k[:22]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step'].items()})
+    print('   ', {k[:22]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step_event_inflated'].items()})
 except Exception as e: print(sys.argv[2], 'FAILED', e)
 PY
 }

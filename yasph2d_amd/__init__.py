@@ -201,6 +201,12 @@ class SphxContext:
     def profile_reset(self):
         self._chk(self.L.sphx_profile_reset(self.h))
 
+    def profile_event_overhead(self):
+        """Mean elapsed ms of an EMPTY hipEvent bracket on the context's stream (what the bracket adds to a timed launch)."""
+        v = C.c_double()
+        self._chk(self.L.sphx_profile_event_overhead(self.h, C.byref(v)))
+        return v.value
+
     def profile_get(self):
         n = C.c_uint32(0)
         self._chk(self.L.sphx_profile_get(self.h, None, C.byref(n)))

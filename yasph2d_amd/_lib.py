@@ -59,7 +59,7 @@ class SphxStepStats(C.Structure):
         ("dt", C.c_float),
         ("vmax", C.c_float),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("remote_entries", C.c_uint32),
         ("neighbor_entries", C.c_uint64),
     ]
 
@@ -155,6 +155,7 @@ SIGNATURES = {
     "sphx_profile_reset": (_i, [_vp]),
     "sphx_profile_filter": (_i, [_vp, C.c_char_p, _u32]),
     "sphx_profile_get": (_i, [_vp, _vp, C.POINTER(_u32)]),
+    "sphx_profile_event_overhead": (_i, [_vp, C.POINTER(C.c_double)]),
     "sphx_multi_default_options": (_i, [C.POINTER(SphxMultiOptions)]),
     "sphx_multi_create": (_i, [C.POINTER(SphxParams), C.POINTER(C.c_int), _i, C.POINTER(SphxMultiOptions), C.POINTER(_vp)]),
     "sphx_multi_create_rank": (_i, [C.POINTER(SphxParams), _i, C.POINTER(SphxCommOps), C.c_char_p, _i, _i, C.POINTER(SphxMultiOptions), C.POINTER(_vp)]),
@@ -172,6 +173,7 @@ SIGNATURES = {
     "sphx_multi_download": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "sphx_multi_info": (_i, [_vp, C.POINTER(SphxMultiInfo)]),
     "sphx_multi_tile_ctx": (_vp, [_vp, _u32]),
+    "sphx_multi_simulation_step": (_i, [_vp, _vp, _f, C.POINTER(SphxStepStats)]),
     # host mirror
     "sphx_world_create": (_vp, [_f, _f, _f]),
     "sphx_world_destroy": (None, [_vp]),

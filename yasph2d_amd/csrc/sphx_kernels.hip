@@ -1219,9 +1219,9 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
 #ifndef NB_BATCH
 #define NB_BATCH 4
 #endif
-constexpr uint32_t STAGE_SLOTS = LIST_WIN + REMOTE_CAP;
-static_assert((STAGE_SLOTS & (STAGE_SLOTS - 1)) == 0, "don't-care list entries are masked into the staging area");
-static_assert(LIST_WIN % 256 == 0 && REMOTE_CAP % 256 == 0 && STAGE_ROWS % 4 == 0, "staging loops / packed groups");
+constexpr uint32_t next_pow2(uint32_t v) { return v <= 1u ? 1u : 2u * next_pow2((v + 1u) / 2u); }
+constexpr uint32_t STAGE_SLOTS = next_pow2(LIST_WIN + REMOTE_CAP);  // LDS staging area (power of two: don't-care list entries are masked into it)
+static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % 4 == 0 && LIST_WIN + REMOTE_CAP <= 65536, "staging loops / packed groups / 16-bit slots");
 constexpr uint32_t NB_G0 = 3;  // packed 4-entry groups every traversal loads up front (12 entries; the rest on demand)
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1272,7 +1272,7 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
 template <class L, class S>
 __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
     if (h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
-    constexpr uint32_t NW = LIST_WIN / 256, NR = WAVE_REMOTE / 64;
+    constexpr uint32_t NW = (LIST_WIN + 255) / 256, NR = WAVE_REMOTE / 64;
     const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
     uint32_t g[NR];
 #pragma unroll

@@ -321,6 +321,7 @@ struct LocalComm : Comm {
         hipEventDestroy(sh->slot[rank].drained);
     }
     int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+        if (world == 1) return SPHX_OK;
         LocalShared::Slot& me = sh->slot[rank];
         me.peers = peers;
         me.send = send;
@@ -343,6 +344,10 @@ struct LocalComm : Comm {
         return SPHX_OK;
     }
     int allreduce(const double* in, int n, int op, double* out) override {
+        if (world == 1) {
+            for (int k = 0; k < n; ++k) out[k] = in[k];
+            return SPHX_OK;
+        }
         for (int k = 0; k < n; ++k) sh->slot[rank].val[k] = in[k];
         if (!sh->barrier()) return SPHX_ERR_NOT_READY;
         for (int k = 0; k < n; ++k) {
@@ -977,6 +982,18 @@ int sphx_multi_clear_cached(sphx_multi* m) {
         t->num_divergence_iters = 0;
     }
     return SPHX_OK;
+}
+
+// Solver::simulation_step(&mut world, &mut time_manager) in one call: phase A, the caller's TimeManager (its host mirror here:
+// dfsph.rs:433 simulation_step(), :478-480 update_simulation_step), phase B — no round trip through the caller in between.
+int sphx_multi_simulation_step(sphx_multi* m, sphx_timer* timer, float particle_diameter, sphx_step_stats* out_stats) {
+    if (!m || !timer) return SPHX_ERR_INVALID_ARGUMENT;
+    const float dt_prev = sphx_duration_as_secs_f32(sphx_timer_simulation_step_ns(timer));
+    float vmax = 0;
+    int rc = sphx_multi_step_begin(m, dt_prev, &vmax);
+    if (rc) return rc;
+    const uint64_t dt_ns = sphx_timer_update_simulation_step(timer, particle_diameter, vmax);
+    return sphx_multi_step_finish(m, sphx_duration_as_secs_f32(dt_ns), out_stats);
 }
 
 int sphx_multi_synchronize(sphx_multi* m) {

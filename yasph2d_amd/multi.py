@@ -168,13 +168,11 @@ class MultiSolver:
 
     def step(self, timer, diameter=np.float32(0.01)):
         """Solver::simulation_step with the host mirror of the caller's TimeManager in the middle (dfsph.rs:478-480)."""
-        from . import duration_as_secs_f32
-
-        vmax = self.step_begin(timer.simulation_step())
-        dt_ns = timer.update_simulation_step(diameter, vmax)
-        st = self.step_finish(duration_as_secs_f32(dt_ns))
-        st["dt_ns"] = dt_ns
-        return st
+        st = SphxStepStats()
+        self._chk(self.L.sphx_multi_simulation_step(self.h, timer.h, diameter, C.byref(st)))
+        d = st.as_dict()
+        d["dt_ns"] = timer.simulation_step_ns()
+        return d
 
     def synchronize(self):
         self._chk(self.L.sphx_multi_synchronize(self.h))
