@@ -32,7 +32,8 @@ for k, label in NAMES.items():
     if k in fetch or k in write:
         f, w = fetch.get(k, 0), write.get(k, 0)
         res[label] = {"fetch": f, "write": w, "total": f + w}
-scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0), "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0)}
+scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0) + fetch.get("k_scan_onepass", 0),
+        "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0) + write.get("k_scan_onepass", 0)}
 scan["total"] = scan["fetch"] + scan["write"]
 res["cell_scan"] = scan
 json.dump({"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}, open(sys.argv[4], "w"), indent=1)

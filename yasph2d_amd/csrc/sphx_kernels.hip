@@ -993,7 +993,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
             // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
             // itself: an LDS round trip, five exec-mask branches and a vmcnt(0) wait per candidate.)  A cell holds ~3-4 particles, so
             // a cell is usually one trip: four window reads in flight together, four distance tests, and an ORDERED branch-free
-            // append: every lane writes all four slots, the rejected ones to a dump row.
+            // append: every lane writes all four candidates in order (see below).
             // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28);
             // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
             // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
@@ -1025,8 +1025,10 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
                     c[u + 1] = c[u] + (acc[u] ? 1u : 0u);
                 }
                 const uint32_t j0 = w0 + (uint32_t)((int32_t)ab >> 3);
+                // every candidate is WRITTEN to the row the running count points at; a rejected one is overwritten by the next accepted
+                // one (the count has not moved), an accepted one is safe (the count moves past it).  Row STAGE_ROWS absorbs the rest.
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) mytile[(acc[u] ? min(c[u], STAGE_ROWS) : STAGE_ROWS) * 64u] = j0 + u;  // row STAGE_ROWS: dump
+                for (uint32_t u = 0; u < 4; ++u) mytile[min(c[u], STAGE_ROWS) * 64u] = j0 + u;
                 if (c[4] > STAGE_ROWS) {  // rare: rows past the staged ones live in global memory (32-bit, at their wide address)
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u)
@@ -1569,13 +1571,22 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
     float4 pv = PV[il];  // requested before the reduction is read: one round trip, not two
     const float2 a = accel[il];
     if (va.enabled) {
-        const uint32_t b = wave_vmax_get(scal, va.vslot);
-        unsigned long long ns = 0;
-        if (law.enabled) {
-            ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
-            dt = duration_as_secs_f32(ns);
+        // one wavefront per workgroup reads the stripes and applies the timer law (64-bit divisions: ~150 instructions); the others
+        // get dt through LDS
+        __shared__ float dt_s;
+        if (threadIdx.x < 64) {
+            const uint32_t b = wave_vmax_get(scal, va.vslot);
+            unsigned long long ns = 0;
+            float d = dt;
+            if (law.enabled) {
+                ns = timer_law_step_ns(law, sqrtf(__uint_as_float(b)));
+                d = duration_as_secs_f32(ns);
+            }
+            if (threadIdx.x == 0) dt_s = d;
+            if (blockIdx.x == 0) vmax_publish(scal, va, b, law, ns, d);
         }
-        if (blockIdx.x == 0 && threadIdx.x < 64) vmax_publish(scal, va, b, law, ns, dt);
+        __syncthreads();
+        dt = dt_s;
     }
     if (i >= n) return;
     pv.z = pv.z + a.x * dt;
