@@ -145,6 +145,10 @@ def main():
                     help="run exactly ID constant-density and IV divergence iterations per step (0 0 = adaptive, the reference's behaviour)")
     ap.add_argument("--tolerance-scale", type=float, default=1.0,
                     help="multiply both solver tolerances (dfsph.rs:49,53) by this; < 1 makes the loops iterate (the iterating-regime window)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="run a scratch context for this long before the measured one is created (GPU clocks / first-touch; 0 = off)")
+    ap.add_argument("--abi-calls", action="store_true", help="drive the two-phase C ABI from Python (one ctypes call per phase) instead of "
+                                                             "the host mirror's one call per step (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -230,20 +234,51 @@ def main():
         params.list_span_limit = y.LISTS_32BIT
     if args.solver == "wcsph" and (world > 1 or args.force_tiles):
         raise SystemExit("--solver wcsph runs on one GPU")
+    if args.prewarm_ms > 0:
+        # Clock / page warm-up on a SCRATCH context (its own small scene, destroyed before the measured one exists): a fresh box runs
+        # its first few hundred milliseconds of kernels at lower clocks, and W = 5 warm-up steps are 1 ms.  The measured context still
+        # does exactly --warmup untimed and --steps timed steps from t = 0.
+        sw = y.FluidParticleWorld()
+        sw.reset_fluid(float(np.sqrt(min(args.particles, 1_000_000) / 4050.0)))
+        sctx = y.SphxContext(y.default_params(device=dev_index))
+        sctx.set_boundary(sw.boundary_particles)
+        sctx.upload(sw.positions)
+        stimer = y.TimeManager()
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                v = sctx.step_begin(stimer.simulation_step(), stimer.law(diam))
+                sctx.step_finish(y.duration_as_secs_f32(stimer.update_simulation_step(diam, v)))
+        sctx.synchronize()
+        sctx.close()
+        del sw, sctx, stimer
     multi = None
     if world == 1 and not args.force_tiles:
-        ctx = y.SphxContext(params)
-        ctx.set_boundary(boundary)
-        ctx.upload(pos)
         n = n_global
+        if args.no_device_dt or args.abi_calls:
+            # the raw two-phase C ABI, one ctypes call per phase (A/B runs)
+            ctx = y.SphxContext(params)
+            ctx.set_boundary(boundary)
+            ctx.upload(pos)
 
-        def one_step():
-            if args.solver == "wcsph":
-                vmax = ctx.wcsph_step_begin(timer.simulation_step())
-                return ctx.wcsph_step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
-            vmax = ctx.step_begin(timer.simulation_step(), None if args.no_device_dt else timer.law(diam))
-            dt_ns = timer.update_simulation_step(diam, vmax)
-            return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+            def one_step():
+                if args.solver == "wcsph":
+                    vmax = ctx.wcsph_step_begin(timer.simulation_step())
+                    return ctx.wcsph_step_finish(y.duration_as_secs_f32(timer.update_simulation_step(diam, vmax)))
+                vmax = ctx.step_begin(timer.simulation_step(), None if args.no_device_dt else timer.law(diam))
+                dt_ns = timer.update_simulation_step(diam, vmax)
+                return ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+
+        else:
+            # Solver::simulation_step(&mut world, &mut time_manager) through the host-side mirror of the shim (sph::HipDfsphSolver,
+            # csrc/sphx_host.cpp — the C++ twin of the Rust impl in INTEGRATION.md): world, TimeManager and solver object live behind
+            # the boundary, one call per step, positions stay device-resident (sync_world = 0).  The arrays are uploaded by the first
+            # (warm-up) step, like the reference reads its Vecs.
+            solver = (y.WCSPHSolver if args.solver == "wcsph" else y.DFSPHSolver)(w, params)
+            ctx = solver.context()
+
+            def one_step():
+                return solver.simulation_step(w, timer, sync_world=False)
 
     else:
         # The tile step loop runs INSIDE libsphx (sphx_multi, csrc/sphx_tiles.cpp): this process holds one tile.  Transport of the halo
@@ -405,6 +440,7 @@ def main():
                             + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
+                "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
                 "particles_total": n_global,
                 "parallelism": "single GPU" if multi is None else
                 f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
