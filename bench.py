@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "torch"],
                     help="halo records: libsphx's own grouped ncclSend/ncclRecv (rccl; auto with --backend nccl) or torch.distributed "
                          "through the sphx_comm_ops table (torch; always with gloo)")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="halo records on a second stream while the tile counts the cells of the particles it kept (multi-GPU)")
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
@@ -288,7 +290,7 @@ def main():
         from yasph2d_amd.multi import MultiSolver, TorchCommOps
 
         lay = {"auto": ylib.LAYOUT_AUTO, "strips": ylib.LAYOUT_STRIPS, "grid": ylib.LAYOUT_GRID}[args.tiles]
-        kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay)
+        kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay, overlap_exchange=args.overlap_exchange)
         job = "bench" + os.environ.get("MASTER_PORT", "0")
         if dist is None:
             multi = MultiSolver(params, devices=[dev_index], **kw)  # --force-tiles: one tile, the tile code path

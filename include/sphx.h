@@ -216,6 +216,7 @@ int sphx_tile_upload(sphx_ctx* ctx, const float* pos_xy, const float* vel_xy, co
 #define SPHX_HALO_RECORD_BYTES 32 /* {float4 pos+vel, u32 id, f32 kappa, f32 stiffness, u32 pad}; record 0 = header (count in .id) */
 int sphx_tile_pack(sphx_ctx* ctx, void* d_send_left, void* d_send_right, uint32_t cap_records);              /* DEVICE buffers, (1+cap)*32 B */
 int sphx_tile_apply(sphx_ctx* ctx, const void* d_from_left, const void* d_from_right, uint32_t cap_records); /* DEVICE buffers or NULL */
+int sphx_tile_count_kept(sphx_ctx* ctx); /* between pack and apply: cell count of the kept particles, overlapping the exchange */
 int sphx_sub_regrid(sphx_ctx* ctx, uint32_t* out_n_local);                 /* dfsph.rs:512-518 on owned + ghosts */
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
@@ -237,7 +238,8 @@ typedef struct sphx_multi_options {
     uint32_t rebalance_every;  /* steps between re-partitions of the cuts (16; 0 = never) */
     uint32_t layout;           /* SPHX_LAYOUT_* (auto: 2x2 on 4 tiles, strips otherwise) */
     uint32_t cap_records;      /* records per halo buffer (0 = estimated from the uploaded scene) */
-    uint32_t reserved[3];
+    uint32_t overlap_exchange; /* 1: halo records on a second stream, the re-grid's cell count of the kept particles meanwhile */
+    uint32_t reserved[2];
 } sphx_multi_options;
 /* Communicator supplied by the caller for one tile of a multi-process run (NULL: the built-in one — grouped ncclSend/ncclRecv over
  * RCCL for the halo records, the shared-memory all-reduce below for the scalars).  exchange: send d_send[k] to rank peers[k] and

@@ -68,13 +68,15 @@ def test_in_process_strips_bit_exact_vs_reference_loop(world, axis, halo, fixed,
     assert m.info()["transport"].startswith("in-process")
 
 
-def test_in_process_2x2_through_the_impact_bit_exact_vs_reference_loop():
-    """SURVEY.md 8(e) "4 GPUs: 2x2 tiles": warm starts, diagonal migration, budget-triggered extra exchanges, re-partitioning."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_in_process_2x2_through_the_impact_bit_exact_vs_reference_loop(overlap):
+    """SURVEY.md 8(e) "4 GPUs: 2x2 tiles": warm starts, diagonal migration, budget-triggered extra exchanges, re-partitioning.
+    overlap: the halo records travel on a second stream while the tile counts the cells of the particles it kept."""
     pos, boundary = dam_break(2.0)
     lay = GridLayout.quantile(pos, 2, 2)
     kw = dict(halo=10, fixed=(3, 2), rebalance_every=4, layout=lambda: GridLayout(lay.xcuts, lay.ycuts), adaptive_halo=True)
     o, final = oracle_tiles(pos, boundary, 4, None, 150, **kw)
-    m = MultiSolver(y.default_params(fixed_iterations=(3, 2)), devices=[0, 0, 0, 0], halo=10, rebalance_every=4)
+    m = MultiSolver(y.default_params(fixed_iterations=(3, 2)), devices=[0, 0, 0, 0], halo=10, rebalance_every=4, overlap_exchange=overlap)
     m.set_grid(lay.xcuts, lay.ycuts)
     m.set_boundary(boundary)
     m.upload(pos)

@@ -81,7 +81,7 @@ def build(force=False):
 
 class SphxMultiOptions(C.Structure):
     _fields_ = [("halo_cells", C.c_uint32), ("fixed_halo", C.c_uint32), ("rebalance_every", C.c_uint32), ("layout", C.c_uint32),
-                ("cap_records", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("cap_records", C.c_uint32), ("overlap_exchange", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 COMM_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p)
@@ -134,6 +134,7 @@ SIGNATURES = {
     "sphx_tile_upload": (_i, [_vp, _vp, _vp, _vp, _u32]),
     "sphx_tile_pack": (_i, [_vp, _vp, _vp, _u32]),
     "sphx_tile_apply": (_i, [_vp, _vp, _vp, _u32]),
+    "sphx_tile_count_kept": (_i, [_vp]),
     "sphx_sub_regrid": (_i, [_vp, C.POINTER(_u32)]),
     "sphx_sub_nonpressure": (_i, [_vp, _f, C.POINTER(_f)]),
     "sphx_sub_predict": (_i, [_vp, _f]),

@@ -491,12 +491,14 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
     base = __shfl(base, start, 64);
     if (live) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
 }
+// first: the pass covers particles [first, n) (the tile path counts the particles it kept while the halo exchange is in flight and
+// the received ones afterwards)
 template <bool ADVECT>
 __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV, const float2* __restrict__ pos_in,
                                                     uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
                                                     uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
-                                                    DevScalars* __restrict__ scal) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+                                                    DevScalars* __restrict__ scal, uint32_t first) {
+    const uint32_t i = first + xcd_bid() * 256 + threadIdx.x;
     float2 p = make_float2(0.0f, 0.0f);
     if (i < n) {
         if (ADVECT) {

@@ -369,7 +369,8 @@ struct TileDriver {
     sphx_multi_options O;
     Layout layout;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
     std::string err;
     uint32_t halo_max = 16, halo_now = 16, min_halo = 6;
     std::vector<int> spent;
@@ -393,6 +394,7 @@ struct TileDriver {
     float step_dt_prev = 0, step_vmax = 0;
     bool in_step = false;
     float pending_advect_dt = 0.0f;
+    bool overlap = false;  // sphx_multi_options.overlap_exchange / SPHX_MULTI_OVERLAP=1: records on a second stream, interior work meanwhile
 
     int fail(int rc, const std::string& what) {
         err = what;
@@ -419,6 +421,9 @@ struct TileDriver {
             if (b.first) hipFree(b.first);
             if (b.second) hipFree(b.second);
         }
+        if (comm_stream) hipStreamDestroy(comm_stream);
+        if (ev_packed) hipEventDestroy(ev_packed);
+        if (ev_exchanged) hipEventDestroy(ev_exchanged);
         if (stream) hipStreamDestroy(stream);
     }
 
@@ -428,6 +433,8 @@ struct TileDriver {
         O = opt;
         device = dev;
         comm = std::move(c);
+        overlap = O.overlap_exchange != 0;
+        if (const char* e = std::getenv("SPHX_MULTI_OVERLAP")) overlap = e[0] == '1';
         halo_max = O.halo_cells ? O.halo_cells : 16;
         min_halo = std::min<uint32_t>(6, halo_max);
         halo_now = halo_max;
@@ -436,7 +443,10 @@ struct TileDriver {
         cell_inv = 1.0f / P.smoothing_length;
         int rc = sphx_create(&P, &ctx);
         if (rc) return fail(rc, sphx_last_error(nullptr));
-        if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail(SPHX_ERR_HIP, "hipStreamCreate");
+        if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_exchanged, hipEventDisableTiming) != hipSuccess)
+            return fail(SPHX_ERR_HIP, "hipStreamCreate / hipEventCreate");
         // the tile's kernels and its communication share one stream: pack -> exchange -> unpack are ordered by the stream
         TCHK(sphx_set_stream(ctx, stream));
         bufs.assign(comm->world, {nullptr, nullptr});
@@ -597,8 +607,22 @@ struct TileDriver {
         } else {
             TCHK(sphx_tile_pack_n(ctx, send.empty() ? &dummy : send.data(), (uint32_t)send.size(), c));
         }
-        rc = comm->exchange(peers, send, recv, bytes, stream);
-        if (rc) return fail(rc, "halo exchange failed");
+        // overlap_exchange: the records travel on a stream of their own (behind the packing kernels, in front of the unpacking one);
+        // meanwhile the tile's stream counts the cells of the particles it kept — the first pass of the re-grid — so the exchange
+        // latency hides behind interior work.  Off by default: with all tiles on ONE GPU (the only hardware this was measured on) the
+        // two cross-stream event hand-offs cost more than the overlapped 8 us of counting (0.47 vs 0.40 ms/step, 2 x 500 k particles);
+        // whether it pays over xGMI has to be measured on a multi-GPU node.
+        if (!peers.empty() && !overlap) {
+            rc = comm->exchange(peers, send, recv, bytes, stream);
+            if (rc) return fail(rc, "halo exchange failed");
+        } else if (!peers.empty()) {
+            if (hipEventRecord(ev_packed, stream) != hipSuccess || hipStreamWaitEvent(comm_stream, ev_packed, 0) != hipSuccess) return fail(SPHX_ERR_HIP, "event (pack -> exchange)");
+            rc = comm->exchange(peers, send, recv, bytes, comm_stream);
+            if (rc) return fail(rc, "halo exchange failed");
+            if (hipEventRecord(ev_exchanged, comm_stream) != hipSuccess) return fail(SPHX_ERR_HIP, "event (exchange -> unpack)");
+            TCHK(sphx_tile_count_kept(ctx));
+            if (hipStreamWaitEvent(stream, ev_exchanged, 0) != hipSuccess) return fail(SPHX_ERR_HIP, "event wait");
+        }
         const void* cdummy = nullptr;
         TCHK(sphx_tile_apply_n(ctx, recv.empty() ? &cdummy : (const void* const*)recv.data(), (uint32_t)recv.size(), c));
         TCHK(sphx_sub_regrid(ctx, &n_local));

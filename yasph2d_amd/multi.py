@@ -94,12 +94,14 @@ class TorchCommOps:
 
 
 class MultiSolver:
-    def __init__(self, params, devices=None, halo=16, fixed_halo=False, rebalance_every=16, layout=_lib.LAYOUT_AUTO, cap_records=0, _rank=None):
+    def __init__(self, params, devices=None, halo=16, fixed_halo=False, rebalance_every=16, layout=_lib.LAYOUT_AUTO, cap_records=0,
+                 overlap_exchange=False, _rank=None):
         self.L = _lib.lib()
         self.params = params
         o = SphxMultiOptions()
         self.L.sphx_multi_default_options(C.byref(o))
         o.halo_cells, o.fixed_halo, o.rebalance_every, o.layout, o.cap_records = halo, int(fixed_halo), rebalance_every, layout, cap_records
+        o.overlap_exchange = int(overlap_exchange)
         self.options = o
         h = C.c_void_p()
         if _rank is None:
