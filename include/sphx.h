@@ -366,6 +366,9 @@ void sphx_timer_on_step_started(sphx_timer* t);                      /* the cloc
 /* DFSPHSolver::new(XSPHViscosityModel::new(h), h) boxed as dyn Solver (main.rs:93-101).  `params` may be NULL (defaults from the world). */
 int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sphx_solver** out);
 int sphx_solver_create_wcsph(const sphx_world* w, const sphx_params* params, sphx_solver** out); /* WCSPHSolver::new, wscsph.rs:29-42 */
+/* the same Box<dyn Solver> over several GPUs (one tile per entry of devices[]; sphx_multi inside): the caller's loop does not change */
+int sphx_solver_create_dfsph_multi(const sphx_world* w, const sphx_params* params, const int* devices, int n_devices,
+                                   const sphx_multi_options* options, sphx_solver** out);
 void sphx_solver_destroy(sphx_solver* s);
 void sphx_solver_clear_cached_data(sphx_solver* s); /* Solver::clear_cached_data */
 /* Solver::simulation_step(&mut world, &mut time_manager) (dfsph.rs:414).  sync_world != 0 copies positions/velocities/

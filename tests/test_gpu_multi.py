@@ -178,3 +178,34 @@ def test_errors_are_reported_not_thrown():
     with pytest.raises(y.SphxError):
         m.step_finish(float("nan"))
     assert v >= 0.0
+
+
+def test_solver_trait_over_a_device_list():
+    """sph::HipDfsphMultiSolver: the caller keeps ONE Box<dyn Solver> and its one simulation_step(&mut world, &mut time_manager) per
+    step (main.rs:50, :279); the device list is an argument of the constructor.  Same bits as driving sphx_multi directly; the world
+    can be synced and edited mid-run like with the single-GPU solver."""
+    w = y.FluidParticleWorld()
+    w.reset_fluid(1.0)
+    pos, boundary = w.positions, w.boundary_particles
+    t = y.TimeManager()
+    s = y.DFSPHMultiSolver(w, devices=[0, 0])
+    stats = [s.simulation_step(w, t, sync_world=False) for _ in range(40)]
+    s.sync_world(w)
+    a = by_id(dict(ids=w.particle_ids, pos=w.positions, vel=w.velocities, density=w.densities))
+    m = MultiSolver(y.default_params(), devices=[0, 0])
+    m.set_boundary(boundary)
+    m.upload(pos)
+    t2 = y.TimeManager()
+    ref = [m.step(t2) for _ in range(40)]
+    b = by_id(m.download())
+    np.testing.assert_array_equal(a["ids"], b["ids"])
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+    assert [x["divergence_iterations"] for x in stats] == [x["divergence_iterations"] for x in ref]
+    assert t.simulation_step_ns() == t2.simulation_step_ns()
+    # the caller edits the (synced) world: a fresh decomposition, the run goes on
+    w.add_fluid_rect(1.2, 1.0, 0.2, 0.2, 0.05)
+    n2 = w.num_dynamic_particles
+    for _ in range(10):
+        s.simulation_step(w, t, sync_world=True)
+    assert w.num_dynamic_particles == n2 > len(pos) and np.isfinite(w.positions).all()

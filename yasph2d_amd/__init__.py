@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_NEIGHBOR_CAP, FLAG_STRAY_PARTICLES, FLAG_WARMUP, KERNEL_POLY6,  # noqa: F401
                    KERNEL_SPIKY, KERNEL_WENDLAND_C2, SphxError, SphxKernelTime, SphxParams, SphxStepStats)
 
-__all__ = ["SphxContext", "FluidParticleWorld", "TimeManager", "DFSPHSolver", "default_params", "duration_from_secs_f32",
+__all__ = ["SphxContext", "FluidParticleWorld", "TimeManager", "DFSPHSolver", "DFSPHMultiSolver", "default_params", "duration_from_secs_f32",
            "duration_as_secs_f32", "SphxError", "WCSPHSolver"]
 
 
@@ -405,6 +405,21 @@ class DFSPHSolver:
         ctx._owned = False
         ctx.h = C.c_void_p(self.L.sphx_solver_ctx(self.h))
         return ctx
+
+
+class DFSPHMultiSolver(DFSPHSolver):
+    """The same Box<dyn Solver> over several GPUs (sph::HipDfsphMultiSolver): simulation_step / clear_cached_data / sync_world as before,
+    the tiles, the halo exchange and the reductions live inside libsphx (sphx_multi)."""
+
+    def __init__(self, world, devices, params=None, options=None):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self.L.sphx_solver_create_dfsph_multi(world.h, C.byref(params) if params is not None else None, devs, len(devices),
+                                                   C.byref(options) if options is not None else None, C.byref(h))
+        if rc:
+            raise SphxError(rc, self.L.sphx_multi_last_error(None).decode())
+        self.h = h
 
 
 class WCSPHSolver(DFSPHSolver):

@@ -207,6 +207,7 @@ SIGNATURES = {
     "sphx_timer_num_steps": (_u32, [_vp]),
     "sphx_solver_create_dfsph": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(_vp)]),
     "sphx_solver_create_wcsph": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(_vp)]),
+    "sphx_solver_create_dfsph_multi": (_i, [_vp, C.POINTER(SphxParams), C.POINTER(C.c_int), _i, C.POINTER(SphxMultiOptions), C.POINTER(_vp)]),
     "sphx_wcsph_step_begin": (_i, [_vp, _f, C.POINTER(_f)]),
     "sphx_wcsph_step_finish": (_i, [_vp, _f, C.POINTER(SphxStepStats)]),
     "sphx_solver_destroy": (None, [_vp]),

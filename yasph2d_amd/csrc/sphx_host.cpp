@@ -223,7 +223,7 @@ void TimeManager::on_step_started() {
 }
 
 // ---- HipDfsphSolver -----------------------------------------------------------------------------------------------------
-HipDfsphSolver::HipDfsphSolver(const FluidParticleWorld& world, const sphx_params* params) {
+sphx_params HipDfsphSolver::params_of(const FluidParticleWorld& world, const sphx_params* params) {
     sphx_params p;
     if (params) {
         p = *params;
@@ -236,6 +236,11 @@ HipDfsphSolver::HipDfsphSolver(const FluidParticleWorld& world, const sphx_param
         p.gravity[0] = world.gravity.x;
         p.gravity[1] = world.gravity.y;
     }
+    return p;
+}
+
+HipDfsphSolver::HipDfsphSolver(const FluidParticleWorld& world, const sphx_params* params) {
+    const sphx_params p = params_of(world, params);
     last_status = sphx_create(&p, &ctx_);
     if (last_status != SPHX_OK) {
         last_error = sphx_last_error(nullptr);
@@ -307,6 +312,78 @@ int HipDfsphSolver::device_step(FluidParticleWorld& w, TimeManager& tm) {
     if ((rc = sphx_step_begin_law(ctx_, dt_prev, use_timer_law ? &law : nullptr, &vmax))) return rc;
     const Real dt = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // dfsph.rs:478-480
     return sphx_step_finish(ctx_, dt, &last_stats);
+}
+
+// ---- HipDfsphMultiSolver ------------------------------------------------------------------------------------------------------
+HipDfsphMultiSolver::HipDfsphMultiSolver(const FluidParticleWorld& world, const sphx_params* params, const int* devices, int n_devices,
+                                         const sphx_multi_options* options)
+    : HipDfsphSolver(NoContext{}) {
+    const sphx_params p = params_of(world, params);
+    last_status = sphx_multi_create(&p, devices, n_devices, options, &multi_);
+    if (last_status != SPHX_OK) {
+        last_error = sphx_multi_last_error(nullptr);
+        multi_ = nullptr;
+    }
+}
+HipDfsphMultiSolver::~HipDfsphMultiSolver() { sphx_multi_destroy(multi_); }
+
+void HipDfsphMultiSolver::clear_cached_data() {
+    if (!multi_) return;
+    last_status = sphx_multi_clear_cached(multi_);
+    uploaded_n_ = (size_t)-1;
+}
+
+void HipDfsphMultiSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm) {
+    if (!multi_) {
+        last_status = SPHX_ERR_NO_DEVICE;
+        return;
+    }
+    auto fail = [&](int rc) {
+        last_status = rc;
+        last_error = sphx_multi_last_error(multi_);
+    };
+    int rc;
+    const size_t n = w.particles.positions.size();
+    if (w.boundary_changed || n != uploaded_n_ || w.fluid_generation != uploaded_generation_) {
+        // the tiles are cut from the scene: a changed boundary or particle set means a fresh decomposition
+        if (w.stale_prefix) {
+            if ((rc = sync_world(w))) return fail(rc);  // headless steps left the host arrays behind: fetch them before re-cutting
+        }
+        const auto& b = w.particles.boundary_particles;
+        if ((rc = sphx_multi_set_boundary(multi_, b.empty() ? nullptr : &b[0].x, (uint32_t)b.size()))) return fail(rc);
+        w.boundary_changed = false;
+        if (w.particles.velocities.size() != n) w.particles.velocities.resize(n, Vector{0, 0});
+        if ((rc = sphx_multi_upload(multi_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr, nullptr, (uint32_t)n)))
+            return fail(rc);
+        uploaded_n_ = n;
+        uploaded_generation_ = w.fluid_generation;
+    }
+    const Real dt_prev = tm.simulation_step().as_secs_f32();  // dfsph.rs:433
+    Real vmax = 0;
+    if ((rc = sphx_multi_step_begin(multi_, dt_prev, &vmax))) return fail(rc);
+    const Real dt = tm.update_simulation_step(w.properties.particle_radius() * 2.0f, vmax).as_secs_f32();  // dfsph.rs:478-480
+    if ((rc = sphx_multi_step_finish(multi_, dt, &last_stats))) return fail(rc);
+    last_status = SPHX_OK;
+    if (sync_every_step) {
+        if ((rc = sync_world(w))) return fail(rc);
+    } else {
+        w.stale_prefix = n;
+    }
+}
+
+int HipDfsphMultiSolver::sync_world(FluidParticleWorld& w) {
+    if (!multi_) return SPHX_ERR_NO_DEVICE;
+    uint64_t n = sphx_multi_num_owned(multi_);
+    w.particles.positions.resize(n);
+    w.particles.velocities.resize(n);
+    w.particles.densities.resize(n);
+    w.particles.particle_ids.resize(n);
+    const int rc = sphx_multi_download(multi_, n ? &w.particles.positions[0].x : nullptr, n ? &w.particles.velocities[0].x : nullptr,
+                                       n ? w.particles.densities.data() : nullptr, n ? w.particles.particle_ids.data() : nullptr, &n);
+    w.stale_prefix = 0;
+    uploaded_generation_ = w.fluid_generation;
+    uploaded_n_ = n;
+    return rc;
 }
 
 // WCSPHSolver<XSPHViscosityModel>::simulation_step, wscsph.rs:126-179
@@ -435,6 +512,19 @@ int sphx_solver_create_dfsph(const sphx_world* w, const sphx_params* params, sph
         const int rc = s->s.last_status;
         delete s;
         *out = nullptr;
+        return rc;
+    }
+    *out = s;
+    return SPHX_OK;
+}
+int sphx_solver_create_dfsph_multi(const sphx_world* w, const sphx_params* params, const int* devices, int n_devices, const sphx_multi_options* options,
+                                   sphx_solver** out) {
+    if (!w || !out || !devices || n_devices < 1) return SPHX_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    sphx_solver* s = new sphx_solver(new sph::HipDfsphMultiSolver(w->w, params, devices, n_devices, options));
+    if (!s->s.ok()) {
+        const int rc = s->s.last_status;
+        delete s;
         return rc;
     }
     *out = s;

@@ -112,10 +112,10 @@ class HipDfsphSolver : public Solver {
    public:
     HipDfsphSolver(const FluidParticleWorld& world, const sphx_params* params_or_null);
     ~HipDfsphSolver() override;
-    bool ok() const { return ctx_ != nullptr; }
+    virtual bool ok() const { return ctx_ != nullptr; }
     void clear_cached_data() override;
     void simulation_step(FluidParticleWorld& fluid_world, TimeManager& time_manager) override;
-    int sync_world(FluidParticleWorld& fluid_world);  // download positions/velocities/densities into the host world
+    virtual int sync_world(FluidParticleWorld& fluid_world);  // download positions/velocities/densities into the host world
 
     bool sync_every_step = true;   // main.rs draws from the host arrays after each step
     bool use_timer_law = true;     // sphx_step_begin_law: the device derives dt itself, the host only verifies it
@@ -125,10 +125,33 @@ class HipDfsphSolver : public Solver {
     sphx_ctx* ctx() { return ctx_; }
 
    protected:
+    struct NoContext {};
+    explicit HipDfsphSolver(NoContext) {}  // for solvers that hold their device state elsewhere (HipDfsphMultiSolver)
+    static sphx_params params_of(const FluidParticleWorld& world, const sphx_params* params_or_null);
     virtual int device_step(FluidParticleWorld& fluid_world, TimeManager& time_manager);  // the two-phase step on the device
     sphx_ctx* ctx_ = nullptr;
 
    private:
+    uint64_t uploaded_generation_ = 0;
+    size_t uploaded_n_ = (size_t)-1;
+};
+
+// The same Solver over SEVERAL GPUs: main.rs keeps its one Box<dyn Solver> and its one call per step (main.rs:50, :279); the domain
+// decomposition, the halo exchange and the reductions happen inside libsphx (sphx_multi_*, csrc/sphx_tiles.cpp).  `devices`: one
+// HIP device ordinal per tile (an ordinal may repeat).
+class HipDfsphMultiSolver : public HipDfsphSolver {
+   public:
+    HipDfsphMultiSolver(const FluidParticleWorld& world, const sphx_params* params_or_null, const int* devices, int n_devices,
+                        const sphx_multi_options* options_or_null);
+    ~HipDfsphMultiSolver() override;
+    bool ok() const override { return multi_ != nullptr; }
+    void clear_cached_data() override;
+    void simulation_step(FluidParticleWorld& fluid_world, TimeManager& time_manager) override;
+    int sync_world(FluidParticleWorld& fluid_world) override;
+    sphx_multi* multi() { return multi_; }
+
+   private:
+    sphx_multi* multi_ = nullptr;
     uint64_t uploaded_generation_ = 0;
     size_t uploaded_n_ = (size_t)-1;
 };

@@ -552,6 +552,12 @@ struct TileDriver {
             cap = (uint32_t)std::max<uint64_t>(1024, (uint64_t)(near * 1.5) + 1024);
         }
         const uint64_t n_own = mine.size();
+        if (sphx_num_particles(ctx)) {
+            // a fresh decomposition of an edited scene: the tile starts from an empty particle set (the slot-bound warm-start values of
+            // the old decomposition mean nothing for the new one)
+            TCHK(sphx_upload(ctx, nullptr, nullptr, 0));
+            TCHK(sphx_clear_cached(ctx));
+        }
         TCHK(sphx_reserve(ctx, (uint32_t)((uint64_t)(n_own * 1.25) + 2ull * std::max<size_t>(2, peers.size()) * cap + 4096)));
         auto span = [](uint32_t lo, uint32_t hi, uint32_t cnt) { return cnt ? std::max<uint32_t>(1, hi - lo + 1) : 1u; };
         columns[0] = (double)n / span(x0, x1, n);
