@@ -1303,20 +1303,28 @@ __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
 template <class GL, class GG, class C>
 __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& gather_lds, GG&& gather_global, C&& consume) {
     if (!h.wide) {
-        auto group = [&](const uint2 e, uint32_t q) {
-            const uint32_t s4[4] = {e.x & 0xffffu, e.x >> 16, e.y & 0xffffu, e.y >> 16};
-            decltype(gather_lds(0u)) r[4];
+        // entries come four to a word pair, but are consumed two at a time: a wavefront whose longest list has 9 or 10 entries does
+        // 10 entry slots of arithmetic, not 12 (the kernels are bound by vector instructions as much as by bytes)
+        auto pair = [&](uint32_t w2, uint32_t k) {
+            const uint32_t s2[2] = {w2 & 0xffffu, w2 >> 16};
+            decltype(gather_lds(0u)) r[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = gather_lds(s4[u] & (STAGE_SLOTS - 1u));  // entries >= lim hold don't-care values
+            for (int u = 0; u < 2; ++u) r[u] = gather_lds(s2[u] & (STAGE_SLOTS - 1u));  // entries >= lim hold don't-care values
 #pragma unroll
-            for (int u = 0; u < 4; ++u) consume(r[u], 4u * q + (uint32_t)u);
+            for (int u = 0; u < 2; ++u) consume(r[u], k + (uint32_t)u);
         };
 #pragma unroll
         for (uint32_t q = 0; q < NB_G0; ++q) {
             if (!__any(lim > 4u * q)) return;
-            group(h.e[q], q);
+            pair(h.e[q].x, 4u * q);
+            if (!__any(lim > 4u * q + 2u)) return;
+            pair(h.e[q].y, 4u * q + 2u);
         }
-        for (uint32_t q = NB_G0; __any(lim > 4u * q); ++q) group(*(const uint2*)(h.rows + q * 512u + h.lane * 8u), q);
+        for (uint32_t q = NB_G0; __any(lim > 4u * q); ++q) {
+            const uint2 e = *(const uint2*)(h.rows + q * 512u + h.lane * 8u);
+            pair(e.x, 4u * q);
+            if (__any(lim > 4u * q + 2u)) pair(e.y, 4u * q + 2u);
+        }
     } else {
         // round-1 path: 32-bit rows, records gathered from global memory, batches of NB_BATCH with the index loads of the next
         // batch issued behind the gathers of the current one
