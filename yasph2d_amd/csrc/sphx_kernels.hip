@@ -948,100 +948,22 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 #ifndef NB_BOUNDS
 #define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
+// Everything behind the candidate scan of a neighbour build, shared by its two forms (k_neighbor_build: every particle walks
+// its own nine cell ranges; k_neighbor_build2: the particles of a cell share one candidate list): static neighbours, densities and
+// alpha factors, list format and rows, statistics.  On entry tile[w][k][lane] (k < min(ct, STAGE_ROWS); further entries at their
+// 32-bit address in `list`) holds the accepted dynamic neighbours of the lane's particle as slots of the [N|B] arrays, ascending.
 template <bool FUSE>
-__global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
-                                                         GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ remote, float* __restrict__ density,
-                                                         float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
-    if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
-    if (xcd_bid() * 256 >= n) return;
-    __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
-    __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+__device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const GridView& gs,
+                                        uint32_t* __restrict__ list, uint32_t* __restrict__ counts, uint32_t* __restrict__ remote,
+                                        float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
+                                        uint32_t w0, uint32_t wlen, bool live, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
+                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
-    // hundred sorted slots, so the candidate scan below reads LDS instead of issuing ~40 scattered global loads per wave.
-    const uint32_t b0 = xcd_bid() * 256;
-    const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
-    const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
-    SPHX_STAMP_BEGIN()
-    const bool live = i < n;
-    const float2 pi = posA[live ? i : b0];  // own position straight from global memory: the cell look-ups below do not wait for the barrier
-    constexpr uint32_t NWIN = (256 + 2 * WIN_HALO + 255) / 256;
-    float2 wreg[NWIN];
-#pragma unroll
-    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
-    uint32_t cx, cy;
-    cell_of(K, pi, cx, cy);
-    uint32_t slot[9], s[9], e[9];
-    bool maybe_static;
-    slots9(gd, cx, cy, slot, &maybe_static);
-    ranges9(gd, slot, s, e);
-#pragma unroll
-    for (uint32_t u = 0; u < NWIN; ++u)
-        if (threadIdx.x + u * 256u < wlen) win[threadIdx.x + u * 256u] = wreg[u];
-    __syncthreads();
-    SPHX_STAMP(0)
-    uint32_t cd = 0, ct = 0;
     uint32_t* const mytile = &tile[w][0][lane];
-    const uint32_t wlen_b = wlen * 8u;
+    uint32_t cd = 0;
+    uint32_t slot[9], s[9], e[9];
     if (live) {
         uint32_t flags = 0;
-        // phase 1: filter
-        SPHX_STAMP(1)
-#ifndef SPHX_ABL_NOLOOP
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
-            // itself: an LDS round trip, five exec-mask branches and a vmcnt(0) wait per candidate.)  A cell holds ~3-4 particles, so
-            // a cell is usually one trip: four window reads in flight together, four distance tests, and an ORDERED branch-free
-            // append: every lane writes all four candidates in order (see below).
-            // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28);
-            // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
-            // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
-            const uint32_t eb = (e[t] - w0) * 8u;
-            uint32_t ab = (s[t] - w0) * 8u;
-            while (ab != eb) {
-                const uint32_t left = (eb - ab) >> 3;  // >= 1
-                float2 pj[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) pj[u] = lds_read_f2((const float2*)((const char*)win + min(ab + 8u * u, wlen_b)));  // win[wlen]: pad slot
-#ifndef SPHX_ABL_NOFALLBACK  // (timing experiments: tools/ab_build.sh)
-                if (ab >= wlen_b || ab + 24u >= wlen_b) {  // the first (ab "negative": j < w0) or the last of the four lies outside the window
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)
-                        if (ab + 8u * u >= wlen_b && u < left) pj[u] = gat(posA, w0 + (uint32_t)((int32_t)(ab + 8u * u) >> 3));
-                }
-#endif
-                uint32_t c[5];
-                c[0] = ct;
-                bool acc[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    // both components in one packed instruction each (v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations, no fusion)
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
-                    const f32x2 q = d * d;
-                    const float d2 = q.x + q.y;
-                    acc[u] = u < left && d2 <= K.radius_sq && d2 > 1.0e-10f;
-                    c[u + 1] = c[u] + (acc[u] ? 1u : 0u);
-                }
-                const uint32_t j0 = w0 + (uint32_t)((int32_t)ab >> 3);
-                // every candidate is WRITTEN to the row the running count points at; a rejected one is overwritten by the next accepted
-                // one (the count has not moved), an accepted one is safe (the count moves past it).  Row STAGE_ROWS absorbs the rest.
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) mytile[min(c[u], STAGE_ROWS) * 64u] = j0 + u;
-                if (c[4] > STAGE_ROWS) {  // rare: rows past the staged ones live in global memory (32-bit, at their wide address)
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)
-                        if (acc[u] && c[u] >= STAGE_ROWS && c[u] < MAX_NEIGHBORS) list[ell_index(i, c[u])] = j0 + u;
-                }
-                ct = c[4];
-                ab += min(left, 4u) * 8u;
-            }
-        }
-#endif
-        SPHX_STAMP(2)
         ct = min(ct, MAX_NEIGHBORS);
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
@@ -1074,7 +996,6 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
-        SPHX_STAMP(3)
     }
 #ifdef SPHX_ABL_NOPHASE2
     if (false) {
@@ -1129,7 +1050,6 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
         alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
     }
-    SPHX_STAMP(4)
     // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
     // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
     // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
@@ -1196,7 +1116,6 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
             r += rem ? 1u : 0u;
         }
     }
-    SPHX_STAMP(5)
     // total number of list entries and of out-of-window entries (stats only): one pair of striped atomics per wavefront
     unsigned long long tot = ct;
 #pragma unroll
@@ -1205,6 +1124,103 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
         if (tot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, tot);
         if (rtot && !wide) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
     }
+}
+
+template <bool FUSE>
+__global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
+                                                         GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ remote, float* __restrict__ density,
+                                                         float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
+    if (xcd_bid() * 256 >= n) return;
+    __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
+    __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
+    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
+    // hundred sorted slots, so the candidate scan below reads LDS instead of issuing ~40 scattered global loads per wave.
+    const uint32_t b0 = xcd_bid() * 256;
+    const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
+    const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
+    SPHX_STAMP_BEGIN()
+    const bool live = i < n;
+    const float2 pi = posA[live ? i : b0];  // own position straight from global memory: the cell look-ups below do not wait for the barrier
+    constexpr uint32_t NWIN = (256 + 2 * WIN_HALO + 255) / 256;
+    float2 wreg[NWIN];
+#pragma unroll
+    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
+    uint32_t cx, cy;
+    cell_of(K, pi, cx, cy);
+    uint32_t slot[9], s[9], e[9];
+    bool maybe_static;
+    slots9(gd, cx, cy, slot, &maybe_static);
+    ranges9(gd, slot, s, e);
+#pragma unroll
+    for (uint32_t u = 0; u < NWIN; ++u)
+        if (threadIdx.x + u * 256u < wlen) win[threadIdx.x + u * 256u] = wreg[u];
+    __syncthreads();
+    SPHX_STAMP(0)
+    uint32_t ct = 0;
+    uint32_t* const mytile = &tile[w][0][lane];
+    const uint32_t wlen_b = wlen * 8u;
+    if (live) {
+        // phase 1: filter
+        SPHX_STAMP(1)
+#ifndef SPHX_ABL_NOLOOP
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
+            // itself: an LDS round trip, five exec-mask branches and a vmcnt(0) wait per candidate.)  A cell holds ~3-4 particles, so
+            // a cell is usually one trip: four window reads in flight together, four distance tests, and an ORDERED branch-free
+            // append: every lane writes all four candidates in order (see below).
+            // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28);
+            // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
+            // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
+            const uint32_t eb = (e[t] - w0) * 8u;
+            uint32_t ab = (s[t] - w0) * 8u;
+            while (ab != eb) {
+                const uint32_t left = (eb - ab) >> 3;  // >= 1
+                float2 pj[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) pj[u] = lds_read_f2((const float2*)((const char*)win + min(ab + 8u * u, wlen_b)));  // win[wlen]: pad slot
+#ifndef SPHX_ABL_NOFALLBACK  // (timing experiments: tools/ab_build.sh)
+                if (ab >= wlen_b || ab + 24u >= wlen_b) {  // the first (ab "negative": j < w0) or the last of the four lies outside the window
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        if (ab + 8u * u >= wlen_b && u < left) pj[u] = gat(posA, w0 + (uint32_t)((int32_t)(ab + 8u * u) >> 3));
+                }
+#endif
+                uint32_t c[5];
+                c[0] = ct;
+                bool acc[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    // both components in one packed instruction each (v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations, no fusion)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
+                    const f32x2 q = d * d;
+                    const float d2 = q.x + q.y;
+                    acc[u] = u < left && d2 <= K.radius_sq && d2 > 1.0e-10f;
+                    c[u + 1] = c[u] + (acc[u] ? 1u : 0u);
+                }
+                const uint32_t j0 = w0 + (uint32_t)((int32_t)ab >> 3);
+                // every candidate is WRITTEN to the row the running count points at; a rejected one is overwritten by the next accepted
+                // one (the count has not moved), an accepted one is safe (the count moves past it).  Row STAGE_ROWS absorbs the rest.
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) mytile[min(c[u], STAGE_ROWS) * 64u] = j0 + u;
+                if (c[4] > STAGE_ROWS) {  // rare: rows past the staged ones live in global memory (32-bit, at their wide address)
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        if (acc[u] && c[u] >= STAGE_ROWS && c[u] < MAX_NEIGHBORS) list[ell_index(i, c[u])] = j0 + u;
+                }
+                ct = c[4];
+                ab += min(left, 4u) * 8u;
+            }
+        }
+#endif
+    }
+    SPHX_STAMP(2)
+    nb_tail<FUSE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
