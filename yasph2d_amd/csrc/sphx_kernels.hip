@@ -829,7 +829,7 @@ __device__ unsigned long long g_stamp[16];
         __builtin_amdgcn_sched_barrier(0);                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[k], t_ - stamp_prev_);                          \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[k], t_ - stamp_prev_);                          \
         stamp_prev_ = t_;                                                                               \
     }
 #define SPHX_STAMP_BEGIN()                                                                              \
@@ -838,7 +838,7 @@ __device__ unsigned long long g_stamp[16];
         __builtin_amdgcn_sched_barrier(0);                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_)::"memory");             \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[15], 1ull);                                     \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[15], 1ull);                                     \
     }
 #else
 #define SPHX_STAMP(k)
@@ -1221,6 +1221,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     }
     SPHX_STAMP(2)
     nb_tail<FUSE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win);
+    SPHX_STAMP(7)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
