@@ -149,6 +149,8 @@ def main():
                     help="multiply both solver tolerances (dfsph.rs:49,53) by this; < 1 makes the loops iterate (the iterating-regime window)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="run a scratch context for this long before the measured one is created (GPU clocks / first-touch; 0 = off)")
+    ap.add_argument("--per-step-calls", action="store_true", help="timed region: one library call per step from Python instead of one call "
+                    "that runs the K steps (sphx_solver_simulation_steps: the caller's frame loop, main.rs:348-350, inside the library)")
     ap.add_argument("--abi-calls", action="store_true", help="drive the two-phase C ABI from Python (one ctypes call per phase) instead of "
                                                              "the host mirror's one call per step (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,6 +257,7 @@ def main():
         sctx.close()
         del sw, sctx, stimer
     multi = None
+    k_steps = None  # the K timed steps in ONE library call (the caller's frame loop on the library's side), where the path has it
     if world == 1 and not args.force_tiles:
         n = n_global
         if args.no_device_dt or args.abi_calls:
@@ -281,6 +284,9 @@ def main():
 
             def one_step():
                 return solver.simulation_step(w, timer, sync_world=False)
+
+            def k_steps(k):
+                return solver.simulation_steps(w, timer, k, sync_world=False)
 
     else:
         # The tile step loop runs INSIDE libsphx (sphx_multi, csrc/sphx_tiles.cpp): this process holds one tile.  Transport of the halo
@@ -322,6 +328,9 @@ def main():
             st["neighbor_entries"] = 0
             return st
 
+        def k_steps(k):
+            return multi.steps(timer, k, diam)
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -354,8 +363,11 @@ def main():
     stats = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats.append(one_step())
+    if k_steps is not None and not args.per_step_calls:
+        stats = k_steps(args.steps)
+    else:
+        for _ in range(args.steps):
+            stats.append(one_step())
     barrier()
     elapsed = time.perf_counter() - t0
     live = None
@@ -452,6 +464,9 @@ def main():
                 "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
                 "max_density_iterations_seen": int(max(s["density_iterations"] for s in stats)),
                 "max_divergence_iterations_seen": int(max(s["divergence_iterations"] for s in stats)),
+                "host_calls": "one library call runs the K timed steps (sphx_*_simulation_steps: the caller's frame loop, main.rs:348-350, "
+                              "in C; every step is a full Solver::simulation_step)" if (k_steps is not None and not args.per_step_calls)
+                else "one library call per step from Python",
                 "solver_loop": "host-run (SPHX_HOST_LOOP=1)" if os.environ.get("SPHX_HOST_LOOP") == "1" else
                 "device-run (residual test on the device, iterations queued ahead)" if multi is None else "host-run with an all-reduce per iteration",
             },

@@ -288,6 +288,11 @@ sphx_ctx* sphx_multi_tile_ctx(sphx_multi* m, uint32_t local_tile); /* inspection
  * (simulation_step() dfsph.rs:433, update_simulation_step dfsph.rs:478-480), phase B */
 struct sphx_timer;
 int sphx_multi_simulation_step(sphx_multi* m, struct sphx_timer* timer, float particle_diameter, sphx_step_stats* out_stats);
+/* `k` of those back to back — the caller's frame loop (main.rs:348-350 -> single_sim_step, :279) on this side of the boundary, for
+ * hosts whose per-call cost matters (a Python driver).  out_stats: k entries or NULL; *out_done (may be NULL) = steps finished;
+ * stops at the first failing step and returns its code. */
+int sphx_multi_simulation_steps(sphx_multi* m, struct sphx_timer* timer, float particle_diameter, uint32_t k, sphx_step_stats* out_stats,
+                                uint32_t* out_done);
 
 /* ---- single-node scalar reductions through POSIX shared memory ---------------------------------------------------------------
  * The three per-step scalars of the tile driver (vmax, two residual sums) already sit in host memory (pinned mailbox) on every
@@ -374,6 +379,12 @@ void sphx_solver_clear_cached_data(sphx_solver* s); /* Solver::clear_cached_data
 /* Solver::simulation_step(&mut world, &mut time_manager) (dfsph.rs:414).  sync_world != 0 copies positions/velocities/
  * densities back into the host world before returning (what main.rs:242-258 draws from); 0 keeps them device-resident. */
 int sphx_solver_simulation_step(sphx_solver* s, sphx_world* w, sphx_timer* t, int sync_world, sphx_step_stats* out_stats);
+/* `k` consecutive simulation_step calls — the frame loop of main.rs:348-350 (PerformStepAndCallAgain -> single_sim_step, :279) on
+ * this side of the boundary, for hosts whose per-call cost matters (a Python driver: ~8 us a step at 1 M particles).  Nothing is
+ * skipped or batched on the device: it IS the loop `for _ in 0..k { solver.simulation_step(world, timer) }`.  out_stats: k entries
+ * or NULL; *out_done (may be NULL) = steps finished; stops at the first failing step and returns its code. */
+int sphx_solver_simulation_steps(sphx_solver* s, sphx_world* w, sphx_timer* t, int sync_world, uint32_t k, sphx_step_stats* out_stats,
+                                 uint32_t* out_done);
 int sphx_solver_sync_world(sphx_solver* s, sphx_world* w); /* explicit download into the host world */
 sphx_ctx* sphx_solver_ctx(sphx_solver* s);
 const char* sphx_solver_last_error(const sphx_solver* s);

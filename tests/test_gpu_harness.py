@@ -87,3 +87,30 @@ def test_headless_world_is_not_rewound_by_a_mid_run_edit():
     assert ta == tb and len(pa) == len(pb) > 4050
     assert np.array_equal(pa, pb) and np.array_equal(va, vb)
     assert pa[:4050, 1].min() < 0.69, "the first block has been falling for 35 steps, not 10"
+
+
+@pytest.mark.gpu
+def test_frame_loop_call_is_the_same_as_single_calls():
+    """sphx_solver_simulation_steps(k) is `for _ in 0..k { solver.simulation_step(world, timer) }` (main.rs:348-350) on the library's
+    side of the boundary: same stats per step, same bits afterwards, same clock."""
+
+    def run(batched):
+        w = y.FluidParticleWorld()
+        w.reset_fluid(1.0)
+        t = y.TimeManager()
+        s = y.DFSPHSolver(w)
+        if batched:
+            stats = s.simulation_steps(w, t, 12, sync_world=False) + s.simulation_steps(w, t, 18, sync_world=False)
+        else:
+            stats = [s.simulation_step(w, t, sync_world=False) for _ in range(30)]
+        s.sync_world(w)
+        return w.positions, w.velocities, w.densities, t.total_simulated_ns, t.num_steps, stats
+
+    a, b = run(False), run(True)
+    assert a[3] == b[3] and a[4] == b[4] == 30
+    for k in range(3):
+        assert np.array_equal(a[k], b[k])
+    assert a[5] == b[5]
+    w = y.FluidParticleWorld()
+    w.reset_fluid(1.0)
+    assert y.DFSPHSolver(w).simulation_steps(w, y.TimeManager(), 0, sync_world=False) == []

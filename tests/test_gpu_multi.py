@@ -196,7 +196,7 @@ def test_solver_trait_over_a_device_list():
     m.set_boundary(boundary)
     m.upload(pos)
     t2 = y.TimeManager()
-    ref = [m.step(t2) for _ in range(40)]
+    ref = m.steps(t2, 15) + [m.step(t2) for _ in range(10)] + m.steps(t2, 15)  # the frame-loop call = single calls
     b = by_id(m.download())
     np.testing.assert_array_equal(a["ids"], b["ids"])
     for k in ("pos", "vel", "density"):

@@ -392,6 +392,15 @@ class DFSPHSolver:
             raise SphxError(rc, self.L.sphx_solver_last_error(self.h).decode())
         return st.as_dict()
 
+    def simulation_steps(self, world, time_manager, k, sync_world=True):
+        """k consecutive simulation_step calls inside the library (the frame loop of main.rs:348-350); returns the k stats dicts."""
+        st = (SphxStepStats * k)()
+        done = C.c_uint32()
+        rc = self.L.sphx_solver_simulation_steps(self.h, world.h, time_manager.h, int(sync_world), k, st, C.byref(done))
+        if rc:
+            raise SphxError(rc, f"step {done.value} of {k}: " + self.L.sphx_solver_last_error(self.h).decode())
+        return [x.as_dict() for x in st]
+
     def sync_world(self, world):
         rc = self.L.sphx_solver_sync_world(self.h, world.h)
         if rc:

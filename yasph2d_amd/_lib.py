@@ -175,6 +175,7 @@ SIGNATURES = {
     "sphx_multi_info": (_i, [_vp, C.POINTER(SphxMultiInfo)]),
     "sphx_multi_tile_ctx": (_vp, [_vp, _u32]),
     "sphx_multi_simulation_step": (_i, [_vp, _vp, _f, C.POINTER(SphxStepStats)]),
+    "sphx_multi_simulation_steps": (_i, [_vp, _vp, _f, _u32, C.POINTER(SphxStepStats), C.POINTER(_u32)]),
     # host mirror
     "sphx_world_create": (_vp, [_f, _f, _f]),
     "sphx_world_destroy": (None, [_vp]),
@@ -213,6 +214,7 @@ SIGNATURES = {
     "sphx_solver_destroy": (None, [_vp]),
     "sphx_solver_clear_cached_data": (None, [_vp]),
     "sphx_solver_simulation_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(SphxStepStats)]),
+    "sphx_solver_simulation_steps": (_i, [_vp, _vp, _vp, _i, _u32, C.POINTER(SphxStepStats), C.POINTER(_u32)]),
     "sphx_solver_sync_world": (_i, [_vp, _vp]),
     "sphx_solver_ctx": (_vp, [_vp]),
     "sphx_solver_last_error": (C.c_char_p, [_vp]),

@@ -552,6 +552,16 @@ int sphx_solver_simulation_step(sphx_solver* s, sphx_world* w, sphx_timer* t, in
     if (out) *out = s->s.last_stats;
     return s->s.last_status;
 }
+int sphx_solver_simulation_steps(sphx_solver* s, sphx_world* w, sphx_timer* t, int sync_world, uint32_t k, sphx_step_stats* out, uint32_t* out_done) {
+    if (out_done) *out_done = 0;
+    if (!s || !w || !t) return SPHX_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < k; ++i) {
+        const int rc = sphx_solver_simulation_step(s, w, t, sync_world, out ? out + i : nullptr);
+        if (rc) return rc;
+        if (out_done) *out_done = i + 1;
+    }
+    return SPHX_OK;
+}
 int sphx_solver_sync_world(sphx_solver* s, sphx_world* w) { return s->s.sync_world(w->w); }
 sphx_ctx* sphx_solver_ctx(sphx_solver* s) { return s->s.ctx(); }
 const char* sphx_solver_last_error(const sphx_solver* s) { return s->s.last_error.c_str(); }

@@ -1026,6 +1026,17 @@ int sphx_multi_simulation_step(sphx_multi* m, sphx_timer* timer, float particle_
     return sphx_multi_step_finish(m, sphx_duration_as_secs_f32(dt_ns), out_stats);
 }
 
+int sphx_multi_simulation_steps(sphx_multi* m, sphx_timer* timer, float particle_diameter, uint32_t k, sphx_step_stats* out, uint32_t* out_done) {
+    if (out_done) *out_done = 0;
+    if (!m || !timer) return SPHX_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < k; ++i) {
+        const int rc = sphx_multi_simulation_step(m, timer, particle_diameter, out ? out + i : nullptr);
+        if (rc) return rc;
+        if (out_done) *out_done = i + 1;
+    }
+    return SPHX_OK;
+}
+
 int sphx_multi_synchronize(sphx_multi* m) {
     if (!m) return SPHX_ERR_INVALID_ARGUMENT;
     for (auto& t : m->tiles) {

@@ -176,6 +176,13 @@ class MultiSolver:
         d["dt_ns"] = timer.simulation_step_ns()
         return d
 
+    def steps(self, timer, k, diameter=np.float32(0.01)):
+        """k consecutive step() calls inside the library (the frame loop of main.rs:348-350); returns the k stats dicts."""
+        st = (SphxStepStats * k)()
+        done = C.c_uint32()
+        self._chk(self.L.sphx_multi_simulation_steps(self.h, timer.h, diameter, k, st, C.byref(done)))
+        return [x.as_dict() for x in st]
+
     def synchronize(self):
         self._chk(self.L.sphx_multi_synchronize(self.h))
 
