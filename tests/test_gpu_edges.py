@@ -282,3 +282,47 @@ def test_device_run_solver_loops_equal_host_run_loops(monkeypatch):
             assert_bits_equal(da[k], db[k], k)
         for k in ("kappa", "stiffness", "alpha"):
             assert_bits_equal(sa[k], sb[k], k)
+
+
+def test_run_ahead_over_the_step_boundary_changes_nothing(monkeypatch):
+    """sphx_step_finish queues the next step's non-pressure pass behind the divergence iterations it predicts (sphx_ctx::ahead); the
+    next sphx_step_begin adopts it only if nothing touched the context and dt_prev is the dt it was queued with.  Same bits as with
+    SPHX_RUN_AHEAD=0 through the impact (under-predicted loops: the queued pass is discarded), across a boundary edit, a re-upload,
+    a clear_cached_data and a caller that passes a different dt_prev."""
+    pos, boundary = dam_break(1.0)
+
+    def run(ahead):
+        monkeypatch.setenv("SPHX_RUN_AHEAD", "1" if ahead else "0")
+        ctx = y.SphxContext(y.default_params())
+        ctx.set_boundary(boundary)
+        ctx.upload(pos)
+        timer = y.TimeManager()
+        d = np.float32(0.01)
+        counts = []
+
+        def steps(k, dt_prev_override=None):
+            for j in range(k):
+                dtp = timer.simulation_step() if dt_prev_override is None or j else dt_prev_override
+                vmax = ctx.step_begin(dtp, timer.law(d))
+                st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(d, vmax)))
+                counts.append((st["density_iterations"], st["divergence_iterations"], np.float32(st["vmax"]).tobytes()))
+
+        steps(300)                                   # through the impact
+        ctx.set_boundary(boundary[: len(boundary) // 2 * 2 - 40])  # a gap in the wall
+        steps(20)
+        steps(5, dt_prev_override=np.float32(0.0007))  # not the dt the previous finish ran with
+        ctx.clear_cached()
+        steps(10)
+        st = ctx.download()
+        keep = st["ids"] % 3 != 0
+        o = np.argsort(st["ids"][keep])
+        ctx.upload(st["pos"][keep][o], st["vel"][keep][o])
+        steps(20)
+        return ctx.download(), counts
+
+    a, ca = run(True)
+    b, cb = run(False)
+    assert ca == cb and max(c[1] for c in ca) > 3
+    assert np.array_equal(a["ids"], b["ids"])
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)

@@ -254,6 +254,17 @@ struct sphx_ctx {
     uint32_t loop_gen = 0;    // generation counter of the device-run solver loops
     uint32_t res_seq = 0;     // reduction sequence number of the solver iterations (ResArgs)
     uint32_t vmax_seq = 0;    // ... and of the max-velocity reductions (VmaxArgs::vslot = vmax_seq & 3)
+    // Run-ahead over the step boundary: sphx_step_finish queues the NEXT step's non-pressure pass (dfsph.rs:436-477) behind the
+    // divergence iterations it predicts, so the GPU does not idle while the host verifies the loop, returns to the caller and comes
+    // back through sphx_step_begin.  The pass only reads the step's final state and writes accel[] + one vmax slot; it is adopted by
+    // the next sphx_step_begin iff nothing has touched the context in between and dt_prev is the dt it was queued with, and simply
+    // run again otherwise (SPHX_RUN_AHEAD=0: never queued).
+    struct RunAhead {
+        bool queued = false;  // the pass is on the stream and has consumed vmax slot `vslot`
+        bool valid = false;   // ... and nothing has invalidated what it read
+        uint32_t n = 0, dt_bits = 0, vslot = 0;
+    } ahead;
+    int run_ahead = 1;
     int host_loop = 0;        // SPHX_HOST_LOOP=1: the host judges every residual (round-1 behaviour; A/B runs)
     std::string prof_filter;  // sphx_profile_filter: only launches with this label are timed, every prof_every-th of them
     uint32_t prof_every = 1, prof_counter = 0;

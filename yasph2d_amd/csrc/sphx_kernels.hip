@@ -1533,6 +1533,12 @@ __device__ __forceinline__ double residual_sum_f64(unsigned long long hi, unsign
     return ((double)(hi - hi0) * 4294967296.0 + (double)(lo - lo0)) * (1.0 / 16777216.0);
 }
 
+// A non-pressure pass that ran ahead of its step and was discarded (sphx_ctx::ahead) has left its maximum in a slot: cleared before
+// the pass runs again into the same slot, so that every step still consumes exactly one slot of the ring.
+__global__ __launch_bounds__(64) void k_clear_vmax_slot(DevScalars* scal, uint32_t vslot) {
+    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->stripe[threadIdx.x].vmax[vslot & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Reader of the max-velocity reduction when no kernel of the step is queued behind it (plain sphx_step_begin, WCSPH, tiles)
 __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs va) {
     const uint32_t b = wave_vmax_get(scal, va.vslot);
