@@ -4,7 +4,8 @@
 out=$GRAFT_REPO_ROOT/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline"
+# (--prewarm-ms 0: the profile holds the measured context's launches only, not the scratch context's clock warm-up)
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --prewarm-ms 0"
 run() { name=$1; shift; timeout 400 rocprofv3 "$@" --output-format csv -d $out/$name -- $B $ARGS > $out/$name.log 2>&1; echo "$name rc=$?"; }
 ARGS="--steps 100 --warmup 5"
 run stats_1M --kernel-trace --stats
@@ -33,6 +34,7 @@ for n in fetch_1M write_1M fetch_16M write_16M; do f=$(find $out/$n -name "*coun
 for n in sq_1M sq2_1M tcc_1M; do f=$(find $out/$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_table.py $f > $out/$n.txt; done
 python3 tools/make_traffic_json.py $out/fetch_1M.txt $out/write_1M.txt 999698 $out/traffic_1M.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of python3 bench.py), profiles/r02_{fetch,write}_1M.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)" > /dev/null
 python3 tools/make_traffic_json.py $out/fetch_16M.txt $out/write_16M.txt 15996960 $out/traffic_16M.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of python3 bench.py --particles 16000000), profiles/r02_{fetch,write}_16M.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md" > /dev/null
+if [ "$2" = prof ]; then find $out -name "*.csv" -delete; find $out -type d -empty -delete; exit 0; fi
 # bench lines (with roofline + cpu_baseline) of the same build
 b() { name=$1; shift; timeout 600 python3 bench.py "$@" > $out/bench_$name.json 2> $out/bench_$name.err; echo "bench $name rc=$?"; }
 b 1M --steps 100
@@ -41,6 +43,8 @@ b 1M_fixed32 --steps 100 --fixed-iterations 3 2 --no-cpu-baseline
 b 1M_fixed55 --steps 100 --fixed-iterations 5 5 --no-cpu-baseline
 b 1M_window3750 --steps 200 --skip-steps 3750 --no-cpu-baseline
 SPHX_HOST_LOOP=1 b 1M_hostloop_fixed55 --steps 100 --fixed-iterations 5 5 --no-cpu-baseline
+SPHX_RUN_AHEAD=0 b 1M_no_run_ahead --steps 100 --no-cpu-baseline
+b 1M_per_step_calls --steps 100 --per-step-calls --no-cpu-baseline
 b 1M_wcsph --steps 100 --solver wcsph --no-cpu-baseline
 b 64M --steps 5 --warmup 1 --particles 64000000 --no-cpu-baseline --no-roofline
 b 128M --steps 5 --warmup 1 --particles 128000000 --no-cpu-baseline --no-roofline

@@ -3,7 +3,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for mode in single tiles; do
+for mode in ${MODES:-single tiles}; do
   extra=""; [ $mode = tiles ] && extra="--force-tiles"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --steps 100 --warmup 5 --prewarm-ms 0 $extra "$@" > $out/$mode.log 2>&1
   f=$(find $out/$mode -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 $GRAFT_REPO_ROOT/tools/summarize_profile.py $f > $out/$mode.stats.txt
