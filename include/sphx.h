@@ -187,6 +187,9 @@ int sphx_download_neighbors(sphx_ctx* ctx, uint16_t* counts, uint32_t* lists, ui
 /* CompactMortonCellGrid::cells (neighborhood_search.rs:34-37,142-165) incl. the sentinel; which: 0 dynamic, 1 static.
  * Pass NULL arrays to query the count. */
 int sphx_download_cells(sphx_ctx* ctx, int which, uint32_t* first_particle, uint32_t* cidx, uint32_t* out_count);
+/* the cell table behind the grid (which: 0 dynamic, 1 static): out[0] = covered 64x64-cell blocks, out[1] = table
+ * entries (= 4096 x blocks: what every build's histogram scan runs over), out[2], out[3] = extent of the block directory */
+int sphx_grid_info(const sphx_ctx* ctx, int which, uint32_t* out4);
 /* derived kernel constants: out[0..2] = Wendland {h_inv, normalizer, normalizer_grad} (wendland_quintic_c2.rs:24-30),
  * out[3..5] = Poly6 {hsq, normalizer, normalizer_grad} (poly6.rs:16-23) */
 int sphx_get_constants(const sphx_ctx* ctx, float* out6);

@@ -326,3 +326,27 @@ def test_run_ahead_over_the_step_boundary_changes_nothing(monkeypatch):
     assert np.array_equal(a["ids"], b["ids"])
     for k in ("pos", "vel", "density"):
         assert_bits_equal(a[k], b[k], k)
+
+
+def test_cell_table_follows_the_fluid():
+    """A blob in free fall crosses a 64x64-cell block every ~70 steps.  The block directory grows a ring whenever a particle reaches
+    its fringe; every 256 builds the coverage is re-derived from the blocks that hold particles (cover_from_occupancy), so the table
+    — what every build's histogram scan runs over — stays a few blocks instead of everything the blob ever came near.  Same bits as
+    the oracle across the re-covers."""
+    side = 24
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(np.float32)
+    pos = (np.array([3.0, 40.0], np.float32) + g * np.float32(0.0111)).astype(np.float32)
+    ctx, o = pair(pos, None)
+    timer = y.TimeManager()
+    first = None
+    seen = []
+    for s in range(1100):
+        step_both(ctx, o, timer, check=(s % 50 == 0))
+        if first is None:
+            first = ctx.grid_info()["blocks"]
+        seen.append(ctx.grid_info()["blocks"])
+    compare_state(ctx, o, "falling blob")
+    d = ctx.download()
+    assert d["pos"][:, 1].max() < 40.0 - 4 * 1.28, "the blob must have fallen through several blocks"
+    assert max(seen) > 2 * first, "rings were added on the way"
+    assert min(seen[768:]) <= 16 and seen[-1] <= 36, (first, max(seen), seen[-1])

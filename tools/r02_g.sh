@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_harness.py tests/test_gpu_multi.py -x -q -m gpu 2>&1 | tail -3 > gpurun_out/g_pytest.txt
-cat gpurun_out/g_pytest.txt
-S=15.713   # sqrt(1e6/4050)
-for i in 1 2; do
-./yasph2d_amd/sphx_harness --solver dfsph --scale $S --steps 400 --warmup 100 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('harness', d['particles'], d['particle_steps_per_s']/1e9, d['particles']/d['particle_steps_per_s']*1e3)"
-python bench.py --no-cpu-baseline --no-roofline --steps 400 --warmup 100 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('bench', d['config']['particles_total'], d['ms_per_step'], d['value']/1e9)"
+timeout 1200 python -m pytest tests/test_gpu_edges.py tests/test_gpu_parity.py tests/test_gpu_random_scenes.py tests/test_gpu_tiles.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|assert" | head -20
+for a in ; do
+python bench.py --no-cpu-baseline --steps 200 $a | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$a', d['ms_per_step'], d['value']/1e9, {k[:12]:round(v*1000,1) for k,v in d['roofline']['per_kernel_ms_per_step_event_inflated'].items()})"
 done

@@ -186,6 +186,12 @@ class SphxContext:
         self._chk(self.L.sphx_download_cells(self.h, int(static), _p(first), _p(cidx), C.byref(m)))
         return first, cidx
 
+    def grid_info(self, which=0):
+        """Cell table behind the grid: covered blocks, table entries, directory extent (sphx_grid_info)."""
+        out = (C.c_uint32 * 4)()
+        self._chk(self.L.sphx_grid_info(self.h, which, out))
+        return dict(blocks=out[0], entries=out[1], nbx=out[2], nby=out[3])
+
     def constants(self):
         out = np.zeros(6, np.float32)
         self._chk(self.L.sphx_get_constants(self.h, _p(out)))

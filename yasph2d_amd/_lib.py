@@ -128,6 +128,7 @@ SIGNATURES = {
     "sphx_download_solver_state": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_download_neighbors": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
     "sphx_download_cells": (_i, [_vp, _i, _vp, _vp, C.POINTER(_u32)]),
+    "sphx_grid_info": (_i, [_vp, _i, C.POINTER(_u32)]),
     "sphx_get_constants": (_i, [_vp, _vp]),
     "sphx_reserve": (_i, [_vp, _u32]),
     "sphx_tile_configure": (_i, [_vp, _i, _u32, _u32, _u32, _i, _i]),

@@ -186,6 +186,7 @@ struct Grid {
     uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
     std::vector<uint8_t> cover;  // dynamic grid, host side: 0 uncovered / 1 interior / 2 fringe per block of the rectangle (static grid: 0 / 1)
     std::vector<uint32_t> h_dir;  // host copy of dir
+    bool fine_valid = false;      // `fine` holds the cell ranges of a build made with THIS directory
     uint32_t len() const { return nblk * BLOCK_CELLS; }
     GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
 };
@@ -237,6 +238,7 @@ struct sphx_ctx {
     sphx::Grid gdyn, gstat;
     bool have_fluid_bbox = false;
     uint32_t fb[4] = {0, 0, 0, 0};  // fluid cell bbox at upload (x0,y0,x1,y1)
+    uint32_t builds_since_cover = 0;  // dynamic grid: builds since the coverage was last derived from the block occupancy
     bool need_expand = false;       // a particle reached the outer ring of the dynamic directory: grow it before the next build
     bool need_recover = false;      // a particle outran the directory (DF_STRAY): re-cover the true bounding box before the next build
     uint32_t recover_streak = 0;    // builds that still re-cover predictively after strays were seen

@@ -1533,6 +1533,14 @@ __device__ __forceinline__ double residual_sum_f64(unsigned long long hi, unsign
     return ((double)(hi - hi0) * 4294967296.0 + (double)(lo - lo0)) * (1.0 / 16777216.0);
 }
 
+// Which blocks of the cell table hold particles?  Block b = table entries [b * 4096, (b + 1) * 4096): occupied iff the first cell's
+// start differs from the last cell's end (cover_from_occupancy).
+__global__ __launch_bounds__(256) void k_block_occupancy(const uint2* __restrict__ fine, uint32_t nblk, uint8_t* __restrict__ occ) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    occ[b] = fine[(size_t)b * BLOCK_CELLS].x != fine[(size_t)b * BLOCK_CELLS + BLOCK_CELLS - 1].y ? 1 : 0;
+}
+
 // A non-pressure pass that ran ahead of its step and was discarded (sphx_ctx::ahead) has left its maximum in a slot: cleared before
 // the pass runs again into the same slot, so that every step still consumes exactly one slot of the ring.
 __global__ __launch_bounds__(64) void k_clear_vmax_slot(DevScalars* scal, uint32_t vslot) {
