@@ -1814,12 +1814,18 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
     const bool need_verdict = RES && ra.enabled && (blockIdx.x == 0 || (INV_DT && la.enabled && ca.hist != nullptr));
     const bool judge = need_verdict && threadIdx.x < 64;
     __shared__ uint32_t last_s;
-    unsigned long long hi = 0, lo = 0;
+    unsigned long long hi = 0, lo = 0, snap_h = 0, snap_l = 0;
+    uint32_t sticky = 0;
     const uint32_t rp = ra.rseq & 1u;
     if (RES && ra.enabled) {
         // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
         const uint32_t done_before = (la.enabled && la.iter > 1u) ? scal->loop_done : 0u;
-        if (judge) residual_stripe_load(scal, hi, lo);
+        if (judge) {  // everything the verdict needs is requested here, in one round trip, ahead of the staging loads
+            residual_stripe_load(scal, hi, lo);
+            snap_h = scal->snap_hi[rp ^ 1u];
+            snap_l = scal->snap_lo[rp ^ 1u];
+            sticky = scal->flags;
+        }
         if (done_before != 0u && done_before < la.iter) {  // (== iter: workgroup 0 of THIS launch has just recorded its verdict)
             if (blockIdx.x == 0 && threadIdx.x < 64) {  // nothing was added since: the snapshot chain stays intact
                 residual_wave_reduce(hi, lo);
@@ -1857,13 +1863,13 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
         residual_wave_reduce(hi, lo);
-        const double sum64 = residual_sum_f64(hi, lo, scal->snap_hi[rp ^ 1u], scal->snap_lo[rp ^ 1u]);
+        const double sum64 = residual_sum_f64(hi, lo, snap_h, snap_l);
         bool more = false;
         if (la.enabled) {
             // the host's operations: f64 sum rounded once, two f32 divisions, one product
             const float sum = (float)sum64;
             const float avg = DIVERGENCE ? sum / (float)la.n_total / la.rho0 : sum / (float)la.n_total;
-            if ((scal->flags & DF_NONFINITE) || !(fabsf(avg) <= 3.402823466e38f)) {
+            if ((sticky & DF_NONFINITE) || !(fabsf(avg) <= 3.402823466e38f)) {
                 more = false;  // the reference panics (dfsph.rs:223 / :378); the host reports it
             } else if (la.fixed) {
                 more = la.iter < la.fixed;
