@@ -1464,7 +1464,7 @@ __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict
 // called by a whole wavefront; every lane returns the maximum
 __device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t b = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].vmax[vslot & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t b = lane < STRIPES ? scal->stripe[lane].vmax[vslot & 3u] : 0u;  // plain load, as in residual_stripe_load
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
     return b;
@@ -1518,8 +1518,11 @@ __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restri
 // one stripe, (2) every lane gets the cumulative sums
 __device__ __forceinline__ void residual_stripe_load(const DevScalars* __restrict__ scal, unsigned long long& hi, unsigned long long& lo) {
     const uint32_t lane = threadIdx.x & 63u;
-    hi = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    lo = lane < STRIPES ? __hip_atomic_load(&scal->stripe[lane].res_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    // plain loads: the sums were left by the PREVIOUS kernel on the stream (nothing adds to them while this one runs), so every
+    // workgroup of an XCD can take them from that XCD's L2 — agent-scope loads go past the L2 to the fabric, and 4 000 workgroups
+    // asking it for the same 64 lines cost the density correction 2.5 us
+    hi = lane < STRIPES ? scal->stripe[lane].res_hi : 0ull;
+    lo = lane < STRIPES ? scal->stripe[lane].res_lo : 0ull;
 }
 __device__ __forceinline__ void residual_wave_reduce(unsigned long long& hi, unsigned long long& lo) {
 #pragma unroll
@@ -1737,10 +1740,19 @@ template <bool DIVERGENCE>
 __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero,
-                                                        DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la) {
+                                                        DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la,
+                                                        uint32_t* __restrict__ clear_hist, uint32_t clear_len) {
     // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
     if (la.enabled && la.iter > 1u && scal->loop_done != 0u) return;
     if (dt_dev) dt = *dt_dev;
+    // Every density correction of a device-run loop also does the re-grid's cell count (it cannot know early and cheaply whether it
+    // is the last one: deriving the verdict in every workgroup cost that kernel 2.5 us).  This iteration exists, so the previous
+    // correction was not the last: its count is wiped here, a slice per workgroup, before this iteration's correction counts again.
+    if (clear_hist) {
+        const uint32_t per = (clear_len + gridDim.x - 1u) / gridDim.x;
+        const uint32_t c0 = blockIdx.x * per, c1 = min(c0 + per, clear_len);
+        for (uint32_t k = c0 + threadIdx.x; k < c1; k += 256u) clear_hist[k] = 0u;
+    }
     __shared__ float4 rec[STAGE_SLOTS];
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
@@ -1804,16 +1816,13 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         dt = *dt_dev;
         inv_dt = 1.0f / dt;
     }
-    // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs).
-    // Who needs it: workgroup 0 keeps the books (snapshot of the cumulative sums, DevScalars::loop_done) and publishes to the mailbox;
-    // in a device-run loop (LoopArgs) the density correction of every workgroup needs the verdict of dfsph.rs:221-236 (is this the
-    // last iteration?  then it also does the re-grid's advection + cell count).  One wavefront per workgroup derives it (every
-    // workgroup the same value) and hands it to the others through LDS behind the staging barrier; the stripes are requested
+    // This launch sits right behind its iteration's compute_error and READS the residual sum that one left in the stripes (ResArgs):
+    // the first wavefront of workgroup 0 keeps the books (snapshot of the cumulative sums), applies the test of dfsph.rs:221-236 /
+    // :376-391 in a device-run loop (LoopArgs; DevScalars::loop_done) and publishes to the mailbox.  The stripes are requested
     // first and reduced late, so they cost no round trip of their own.
     constexpr bool RES = !WARM;
-    const bool need_verdict = RES && ra.enabled && (blockIdx.x == 0 || (INV_DT && la.enabled && ca.hist != nullptr));
+    const bool need_verdict = RES && ra.enabled && blockIdx.x == 0;
     const bool judge = need_verdict && threadIdx.x < 64;
-    __shared__ uint32_t last_s;
     unsigned long long hi = 0, lo = 0, snap_h = 0, snap_l = 0;
     uint32_t sticky = 0;
     const uint32_t rp = ra.rseq & 1u;
@@ -1879,7 +1888,6 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
                 if (more && la.iter > la.max_iters) more = false;    // dfsph.rs:236 / :391
             }
         }
-        if (threadIdx.x == 0) last_s = more ? 0u : 1u;
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0) {
                 scal->snap_hi[rp] = hi;
@@ -1899,8 +1907,6 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         }
     }
     __syncthreads();
-    // does the loop end with this iteration?  (host-run loops: not known here; every density correction counts)
-    const bool last = (need_verdict && la.enabled) ? last_s != 0u : true;
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
         const uint32_t cd = h.cd, ct = h.ct;
@@ -1953,7 +1959,7 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
     if (!WARM && INV_DT)
-        if (ca.hist && last) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);
+        if (ca.hist) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);  // every density correction counts
 }
 
 // ------------------------------------------------------------------------------------------------------------------
