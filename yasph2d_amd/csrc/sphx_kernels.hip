@@ -441,6 +441,13 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     }
 }
 
+// what a kernel that ends with the re-grid's cell count (count_cell) is handed
+struct CountArgs {
+    GridView g;
+    uint32_t *hist, *cidx, *slot;
+    float dt;  // the step (host value; with dt_dev the device's)
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // grid build: a1 (cell index), a2 (counting sort by Morton key, stable), a3 (gather), a4 (cells = fine table)
 // ------------------------------------------------------------------------------------------------------------------
@@ -707,7 +714,8 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ bl
 // stays as a ghost: the new owner receives the very same record in this exchange but cannot send it back before the next one.
 __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
-                                                    uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt) {
+                                                    uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt, CountArgs ca,
+                                                    DevScalars* __restrict__ scal) {
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -729,8 +737,7 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
         if (lane == 0) wc[w][k] = (uint32_t)__popcll(bal[k]);
     }
     __syncthreads();
-    if (i >= n) return;
-    if (m) {
+    if (i < n && m) {
         const unsigned long long below = (1ull << lane) - 1ull;
         HaloRec r;
         r.pv = pv;
@@ -747,19 +754,26 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
             }
         }
     }
-    const bool valid = (id >> 31) != 0 && pv.x == pv.x;
-    uint32_t cx, cy;
-    cell_of(K, make_float2(pv.x, pv.y), cx, cy);
-    const bool own = rect_has(K.tile, cx, cy, 0u);
-    const bool ghost = rect_has(K.tile, cx, cy, halo);
-    if (valid && own) return;
-    if (valid && ghost) {
-        pid[i] = id & 0x7FFFFFFFu;
-        return;
+    float2 pkeep = make_float2(pv.x, pv.y);  // where the particle is if the tile keeps it (NaN x: retired)
+    if (i < n) {
+        const bool valid = (id >> 31) != 0 && pv.x == pv.x;
+        uint32_t cx, cy;
+        cell_of(K, pkeep, cx, cy);
+        const bool own = rect_has(K.tile, cx, cy, 0u);
+        const bool ghost = rect_has(K.tile, cx, cy, halo);
+        if (valid && own) {
+        } else if (valid && ghost) {
+            pid[i] = id & 0x7FFFFFFFu;
+        } else {
+            const float nan = __uint_as_float(0x7FC00000u);
+            PV[i].x = nan;
+            posA[i].x = nan;
+            pkeep.x = nan;
+        }
     }
-    const float nan = __uint_as_float(0x7FC00000u);
-    PV[i].x = nan;
-    posA[i].x = nan;
+    // first pass of the re-grid that follows the exchange, for the particles the tile keeps: their cell and the histogram (the
+    // arrivals are counted by the re-grid itself; a retired particle has no cell)
+    if (ca.hist) count_cell(K, ca.g, i < n, i, pkeep, ca.hist, ca.cidx, ca.slot, 1u, scal);
 }
 // append the received records (peer after peer, `cap` slots each) behind the current particles; unused slots are marked dropped
 struct TileInbox {
@@ -1802,11 +1816,6 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // correction counts, and the host clears the histogram again when another iteration follows — unless the loop is run by the device
 // (LoopArgs): then the correction derives the verdict from the residual itself and only the last one counts.
 // hist == nullptr: plain correction.
-struct CountArgs {
-    GridView g;
-    uint32_t *hist, *cidx, *slot;
-    float dt;  // the step (host value; with dt_dev the device's)
-};
 template <bool WARM, bool INV_DT>
 __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
