@@ -46,8 +46,11 @@ enum {
     SPHX_FLAG_DENSITY_ITER_CAP = 2u,        /* "Density error correction canceled" (dfsph.rs:236-245) */
     SPHX_FLAG_DIVERGENCE_ITER_CAP = 4u,     /* "Divergence error correction canceled" (dfsph.rs:391-400) */
     SPHX_FLAG_WARMUP = 8u,                  /* this step ran the warm-up block (dfsph.rs:419-428) */
-    SPHX_FLAG_STRAY_PARTICLES = 16u         /* a particle moved more than a 64-cell block beyond the covered region in one step (a blow-up);
+    SPHX_FLAG_STRAY_PARTICLES = 16u,        /* a particle moved more than a 64-cell block beyond the covered region in one step (a blow-up);
                                                it is kept, without neighbours, and the cell directory is re-covered before the next build */
+    SPHX_FLAG_DENSE_CELL = 32u              /* a cell held more than 4096 particles (a collapse to a point, or strays parked together):
+                                               their order INSIDE that cell follows arrival, not the previous index — the stable rank
+                                               costs occupancy^2 loads and would stall the GPU; everything else is unaffected */
 };
 
 /* kernel kinds for sphx_update_densities (src/sph/smoothing_kernel/) */
@@ -187,6 +190,8 @@ int sphx_download_neighbors(sphx_ctx* ctx, uint16_t* counts, uint32_t* lists, ui
 /* CompactMortonCellGrid::cells (neighborhood_search.rs:34-37,142-165) incl. the sentinel; which: 0 dynamic, 1 static.
  * Pass NULL arrays to query the count. */
 int sphx_download_cells(sphx_ctx* ctx, int which, uint32_t* first_particle, uint32_t* cidx, uint32_t* out_count);
+/* SPHX_FLAG_* bits raised since the latest sphx_step_begin (also by the stand-alone sphx_update_neighborhood) */
+uint32_t sphx_last_flags(const sphx_ctx* ctx);
 /* the cell table behind the grid (which: 0 dynamic, 1 static): out[0] = covered 64x64-cell blocks, out[1] = table
  * entries (= 4096 x blocks: what every build's histogram scan runs over), out[2], out[3] = extent of the block directory */
 int sphx_grid_info(const sphx_ctx* ctx, int which, uint32_t* out4);

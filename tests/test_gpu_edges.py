@@ -350,3 +350,46 @@ def test_cell_table_follows_the_fluid():
     assert d["pos"][:, 1].max() < 40.0 - 4 * 1.28, "the blob must have fallen through several blocks"
     assert max(seen) > 2 * first, "rings were added on the way"
     assert min(seen[768:]) <= 16 and seen[-1] <= 36, (first, max(seen), seen[-1])
+
+
+def test_a_cell_with_thousands_of_particles_does_not_stall_the_regrid():
+    """Round-1 review: the stable rank of k_rank_gather is quadratic in the cell occupancy.  40 000 particles collapsed into ONE cell
+    (1.6e9 dependent loads on the old path) must re-grid in milliseconds: past 4096 particles per cell the order inside the cell is
+    the arrival order, the step reports SPHX_FLAG_DENSE_CELL, and nothing else changes — every particle is still there, cells and
+    neighbour counts are what the oracle's are (the lists of such a cell hold the cap's worth of its mates)."""
+    import time
+
+    rng = np.random.default_rng(5)
+    n = 40000
+    blob = (np.array([2.001, 3.001], np.float32) + rng.random((n, 2), dtype=np.float32) * np.float32(0.017)).astype(np.float32)  # inside one 0.02 cell
+    side = 30
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(np.float32)
+    calm = (np.array([4.0, 3.0], np.float32) + g * np.float32(0.0111)).astype(np.float32)
+    pos = np.concatenate([blob, calm])
+    ctx = y.SphxContext()
+    ctx.upload(pos)
+    ctx.update_neighborhood()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.update_neighborhood()
+    ctx.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+    assert ctx.last_flags() & y.FLAG_DENSE_CELL
+    d = ctx.download()
+    assert np.array_equal(np.sort(d["ids"]), np.arange(len(pos)))
+    assert_bits_equal(d["pos"][np.argsort(d["ids"])], pos, "positions follow their ids")
+    first, cidx = ctx.download_cells()
+    occ = np.diff(first)
+    assert occ.max() == n and (occ[occ < n] <= 9).all()
+    nb = ctx.download_neighbors()
+    counts = nb["counts"] if isinstance(nb, dict) else nb[0]
+    assert counts.reshape(-1, 2)[:, 1].max() == 64
+    # the calm patch is ordinary fluid: bit-exact against the oracle on its own
+    o = Oracle()
+    o.set_particles(calm, None)
+    o.update_neighborhood()
+    ctx2 = y.SphxContext()
+    ctx2.upload(calm)
+    ctx2.update_neighborhood()
+    assert not (ctx2.last_flags() & y.FLAG_DENSE_CELL)
+    assert_same_neighbors(ctx2.download_neighbors(), o.neighbors())

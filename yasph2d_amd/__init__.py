@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_NEIGHBOR_CAP, FLAG_STRAY_PARTICLES, FLAG_WARMUP, KERNEL_POLY6,  # noqa: F401
+from ._lib import (FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_DENSE_CELL, FLAG_NEIGHBOR_CAP, FLAG_STRAY_PARTICLES, FLAG_WARMUP, KERNEL_POLY6,  # noqa: F401
                    KERNEL_SPIKY, KERNEL_WENDLAND_C2, SphxError, SphxKernelTime, SphxParams, SphxStepStats)
 
 __all__ = ["SphxContext", "FluidParticleWorld", "TimeManager", "DFSPHSolver", "DFSPHMultiSolver", "default_params", "duration_from_secs_f32",
@@ -185,6 +185,9 @@ class SphxContext:
         cidx = np.zeros(m.value, np.uint32)
         self._chk(self.L.sphx_download_cells(self.h, int(static), _p(first), _p(cidx), C.byref(m)))
         return first, cidx
+
+    def last_flags(self):
+        return self.L.sphx_last_flags(self.h)
 
     def grid_info(self, which=0):
         """Cell table behind the grid: covered blocks, table entries, directory extent (sphx_grid_info)."""

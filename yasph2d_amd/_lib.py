@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (sphx.h)
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY, ERR_NONFINITE, ERR_NEIGHBOR_PANIC, ERR_CAPACITY, ERR_OUT_OF_DOMAIN = range(9)
-FLAG_NEIGHBOR_CAP, FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_WARMUP, FLAG_STRAY_PARTICLES = 1, 2, 4, 8, 16
+FLAG_NEIGHBOR_CAP, FLAG_DENSITY_ITER_CAP, FLAG_DIVERGENCE_ITER_CAP, FLAG_WARMUP, FLAG_STRAY_PARTICLES, FLAG_DENSE_CELL = 1, 2, 4, 8, 16, 32
 KERNEL_WENDLAND_C2, KERNEL_POLY6, KERNEL_SPIKY = 0, 1, 2
 
 
@@ -129,6 +129,7 @@ SIGNATURES = {
     "sphx_download_neighbors": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
     "sphx_download_cells": (_i, [_vp, _i, _vp, _vp, C.POINTER(_u32)]),
     "sphx_grid_info": (_i, [_vp, _i, C.POINTER(_u32)]),
+    "sphx_last_flags": (_u32, [_vp]),
     "sphx_get_constants": (_i, [_vp, _vp]),
     "sphx_reserve": (_i, [_vp, _u32]),
     "sphx_tile_configure": (_i, [_vp, _i, _u32, _u32, _u32, _i, _i]),

@@ -48,7 +48,8 @@ constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2:
 constexpr uint32_t DIR_FRINGE = 0x80000000u;  // directory entry flag: a covered block on the fringe of the fluid (offsets stay < 2^31)
 constexpr uint32_t DIR_STATIC = 1u;  // dynamic directory only: the boundary's directory covers this block too (offsets are multiples of 4096)
 constexpr uint32_t DIR_FLAGS = DIR_FRINGE | DIR_STATIC;
-enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u, DF_NONFINITE = 128u };
+enum : uint32_t { DF_OUT_OF_DOMAIN = 1u, DF_HALO_CAP = 2u, DF_NB_CAP = 4u, DF_NB_PANIC = 8u, DF_NEAR_EDGE = 16u, DF_STRAY = 32u, DF_SCAN_STALL = 64u, DF_NONFINITE = 128u, DF_DENSE_CELL = 256u };
+constexpr uint32_t RANK_LOOP_MAX = 4096;  // k_rank_gather: largest cell whose particles are ranked by previous index (quadratic in the occupancy)
 constexpr uint32_t LOOP_HIST = 512;  // residual sums of the latest solver loop kept in the mailbox (ring; the reference caps a loop at 200 / 400 (+1) iterations)
 
 // Constants every kernel needs; passed by value (kernarg).  Derived exactly like the reference's constructors.

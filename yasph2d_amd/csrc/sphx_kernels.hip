@@ -545,6 +545,7 @@ struct GatherArgs {
     const uint32_t* u_in;  // particle id; bit 31 = owned by this tile
     uint32_t* u_out;
     DevScalars* count_owned;  // tile mode: counts ids with bit 31 set
+    DevScalars* flags;        // DF_DENSE_CELL goes here
     float advect_dt;          // > 0: the fluid build inside a step — positions advance by v*dt while the records move
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
@@ -566,9 +567,17 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     const uint32_t s = se.x;
     uint32_t e = se.y;
     if (e > n) e = n;
-    uint32_t rank = 0;
-    for (uint32_t q = s; q < e; ++q) rank += (order[q] < i) ? 1u : 0u;
-    const uint32_t dst = s + rank;
+    uint32_t dst;
+    if (e - s <= RANK_LOOP_MAX) {
+        uint32_t rank = 0;
+        for (uint32_t q = s; q < e; ++q) rank += (order[q] < i) ? 1u : 0u;
+        dst = s + rank;
+    } else {
+        // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
+        // stall the GPU for seconds.  Its particles stay in arrival order (a valid permutation of the cell's slots); reported.
+        dst = p;
+        if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
+    }
     if (dst >= n) return;
     if (a.pv_in) {
         float4 pv = a.pv_in[i];
