@@ -340,6 +340,7 @@ def main():
     # Warm-up: every launch bracketed by hipEvents on the context's stream -> which kernel dominates a step.  (All ranks take the
     # same decision: the kernel mix is the same on every tile.)
     dominant = None
+    wprof = None
     if not args.no_roofline and args.warmup > 0:
         ctx.profile_reset()
         ctx.profile_filter(None)
@@ -375,6 +376,10 @@ def main():
         ctx.profile_enable(False)
         live = ctx.profile_get().get(dominant)
         ctx.profile_filter(None)
+        live_from = "timed region"
+        if (live is None or not live["launches"]) and wprof and dominant in wprof:
+            # fewer than 4 timed launches of the dominant kernel (--steps < 4): the event-bracketed warm-up steps stand in
+            live, live_from = wprof[dominant], "warm-up steps (the timed region was too short to bracket a launch)"
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,7 +426,8 @@ def main():
             "event_bracket_overhead_ms": ev_ms, "launches": rec["launches"],
             "algorithmic_bytes_per_launch": rec["bytes"] / rec["launches"],
             "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream, minus the "
-                        "elapsed time of an empty event bracket measured in the same process",
+                        "elapsed time of an empty event bracket measured in the same process" if live_from == "timed region" else
+                        "hipEvents around this kernel's launches, minus the elapsed time of an empty event bracket; taken from the " + live_from,
             "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
             "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (each adds the overhead above and keeps "
                     "kernels from overlapping their neighbours' tails): its sum exceeds ms_per_step; information only",
