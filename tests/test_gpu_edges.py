@@ -393,3 +393,33 @@ def test_a_cell_with_thousands_of_particles_does_not_stall_the_regrid():
     ctx2.update_neighborhood()
     assert not (ctx2.last_flags() & y.FLAG_DENSE_CELL)
     assert_same_neighbors(ctx2.download_neighbors(), o.neighbors())
+
+
+def test_divergence_error_folded_into_the_neighbour_build_changes_nothing(monkeypatch):
+    """When the divergence loop starts without a warm start, the neighbour build also does that loop's first compute_density_change
+    (k_neighbor_build<2>: errors, err * alpha, zeroed warm-start stiffness, residual).  SPHX_FUSE_DIV=0 runs the separate kernel.
+    Same bits and counts through the impact, where steps with and without a warm start alternate."""
+    pos, boundary = dam_break(1.0)
+
+    def run(fused):
+        monkeypatch.setenv("SPHX_FUSE_DIV", "1" if fused else "0")
+        ctx = y.SphxContext(y.default_params())
+        ctx.set_boundary(boundary)
+        ctx.upload(pos)
+        timer = y.TimeManager()
+        d = np.float32(0.01)
+        counts = []
+        for _ in range(420):
+            vmax = ctx.step_begin(timer.simulation_step(), timer.law(d))
+            st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(d, vmax)))
+            counts.append((st["density_iterations"], st["divergence_iterations"], st["warmstart_divergence"], np.float32(st["avg_divergence"]).tobytes()))
+        return ctx.download(), ctx.download_solver_state(), counts
+
+    a, sa, ca = run(True)
+    b, sb, cb = run(False)
+    assert ca == cb
+    assert any(c[2] for c in ca) and any(not c[2] for c in ca[100:]), "both kinds of step must occur"
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+    for k in ("kappa", "stiffness", "alpha"):
+        assert_bits_equal(sa[k], sb[k], k)

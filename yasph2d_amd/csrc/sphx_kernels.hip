@@ -975,12 +975,21 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 // its own nine cell ranges; k_neighbor_build2: the particles of a cell share one candidate list): static neighbours, densities and
 // alpha factors, list format and rows, statistics.  On entry tile[w][k][lane] (k < min(ct, STAGE_ROWS); further entries at their
 // 32-bit address in `list`) holds the accepted dynamic neighbours of the lane's particle as slots of the [N|B] arrays, ascending.
-template <bool FUSE>
+// MODE 0: lists only; 1: + densities and alpha factors; 2: + the first compute_density_change of the divergence loop (DivArgs).
+struct DivArgs {
+    const float4* PV;   // sorted records: PV.zw = the velocities the divergence loop starts from
+    float4* PK;         // receives {pos, err * alpha, err} like k_compute_error<true>
+    float* warm_zero;   // warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
+};
+__device__ __forceinline__ void block_residual_add(float e, DevScalars* __restrict__ scal);
+template <int MODE>
 __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const GridView& gs,
                                         uint32_t* __restrict__ list, uint32_t* __restrict__ counts, uint32_t* __restrict__ remote,
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
-                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win) {
+                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv) {
+    constexpr bool FUSE = MODE >= 1;
+    constexpr bool DIV = MODE == 2;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t* const mytile = &tile[w][0][lane];
     uint32_t cd = 0;
@@ -1020,6 +1029,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
     }
+    float div_err = 0.0f;
 #ifdef SPHX_ABL_NOPHASE2
     if (false) {
 #else
@@ -1029,9 +1039,11 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         // four neighbours per trip: their slots and positions are read together; the accumulation stays sequential
         float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
         float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
+        float delta = 0.0f;  // DIV: sum of (v_i - v_j) . grad W_ij, dfsph.rs:249-280, in the order k_compute_error<true> adds it
         for (uint32_t k0 = 0; k0 < ct; k0 += 4) {
             uint32_t j[4];
             float2 rj[4];
+            float2 vj[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) j[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
             if (k0 + 4u > STAGE_ROWS) {
@@ -1045,12 +1057,19 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t wj = j[u] - w0;
                 rj[u] = lds_read_f2(&win[min(wj, wlen)]);
+                if (DIV) vj[u] = lds_read_f2(&vwin[min(wj, wlen)]);
                 far |= k0 + u < ct && wj >= wlen;
             }
             if (far) {
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u)
-                    if (k0 + u < ct && j[u] - w0 >= wlen) rj[u] = gat(posA, j[u]);
+                    if (k0 + u < ct && j[u] - w0 >= wlen) {
+                        rj[u] = gat(posA, j[u]);
+                        if (DIV) {  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
+                            const float4 r = gat(dv.PV, j[u]);
+                            vj[u] = make_float2(r.z, r.w);
+                        }
+                    }
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
@@ -1068,10 +1087,22 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 gsx = on ? t_gsx : gsx;
                 gsy = on ? t_gsy : gsy;
                 gss = on ? t_gss : gss;
+                if (DIV) {  // wendland_grad(ri, rj) = (sg dx, sg dy): the operations of k_compute_error<true>
+                    const float dvx = vi.x - vj[u].x, dvy = vi.y - vj[u].y;
+                    const float t_delta = delta + (dvx * (sg * dx) + dvy * (sg * dy));
+                    delta = on ? t_delta : delta;
+                }
             }
         }
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
-        alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
+        const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
+        alpha[i] = alpha_i;
+        if (DIV) {
+            const float e = ct < 9u ? 0.0f : fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:261, :277-278
+            dv.PK[i] = make_float4(pi.x, pi.y, e * alpha_i, e);
+            dv.warm_zero[i] = 0.0f;
+            div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
+        }
     }
     // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
     // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
@@ -1147,17 +1178,21 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         if (tot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, tot);
         if (rtot && !wide) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
     }
+    // DIV: this launch stands in for the divergence loop's first compute_density_change — its residual goes where that kernel's goes
+    if (DIV) block_residual_add(div_err, scal);
 }
 
-template <bool FUSE>
-__global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd,
-                                                         GridView gs, uint32_t* __restrict__ list, uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ remote, float* __restrict__ density,
-                                                         float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev) {
+// MODE 2 holds a window of velocities next to the window of positions: 25.6 KB of LDS, six workgroups per CU instead of eight
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 6 : 8, MODE == 2 ? 6 : 8))) void k_neighbor_build(
+    const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd, GridView gs, uint32_t* __restrict__ list,
+    uint32_t* __restrict__ counts, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
+    DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
     __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
     __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
+    __shared__ float2 vwin[MODE == 2 ? 256 + 2 * WIN_HALO + 1 : 1];  // MODE 2: their velocities
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
@@ -1172,6 +1207,14 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     float2 wreg[NWIN];
 #pragma unroll
     for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
+    float2 vreg[MODE == 2 ? NWIN : 1];
+    float2 vi = make_float2(0.0f, 0.0f);
+    if (MODE == 2) {
+        const float2* vel = (const float2*)dv.PV + 1;  // PV[k].zw = vel[2 k]
+#pragma unroll
+        for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = vel[2u * (w0 + min(threadIdx.x + u * 256u, wlen - 1u))];
+        vi = vel[2u * (live ? i : b0)];
+    }
     uint32_t cx, cy;
     cell_of(K, pi, cx, cy);
     uint32_t slot[9], s[9], e[9];
@@ -1180,7 +1223,10 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
     ranges9(gd, slot, s, e);
 #pragma unroll
     for (uint32_t u = 0; u < NWIN; ++u)
-        if (threadIdx.x + u * 256u < wlen) win[threadIdx.x + u * 256u] = wreg[u];
+        if (threadIdx.x + u * 256u < wlen) {
+            win[threadIdx.x + u * 256u] = wreg[u];
+            if (MODE == 2) vwin[threadIdx.x + u * 256u] = vreg[u];
+        }
     __syncthreads();
     SPHX_STAMP(0)
     uint32_t ct = 0;
@@ -1243,7 +1289,7 @@ __global__ NB_BOUNDS void k_neighbor_build(const float2* __restrict__ posA, uint
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<FUSE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win);
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv);
     SPHX_STAMP(7)
 }
 
