@@ -226,6 +226,10 @@ int sphx_tile_pack(sphx_ctx* ctx, void* d_send_left, void* d_send_right, uint32_
 int sphx_tile_apply(sphx_ctx* ctx, const void* d_from_left, const void* d_from_right, uint32_t cap_records); /* DEVICE buffers or NULL */
 int sphx_tile_count_kept(sphx_ctx* ctx); /* between pack and apply: cell count of the kept particles, overlapping the exchange */
 int sphx_sub_regrid(sphx_ctx* ctx, uint32_t* out_n_local);                 /* dfsph.rs:512-518 on owned + ghosts */
+/* The same, and the neighbour build also does the first compute_density_change (dfsph.rs:249-280) of the divergence loop that
+ * follows: the next sphx_sub_iteration(divergence = 1, first = 1) then skips that pass.  Only for a loop that starts WITHOUT a
+ * warm start (sphx_sub_warmstart after this call is refused: the pass has already zeroed the warm-start values). */
+int sphx_sub_regrid_div(sphx_ctx* ctx, uint32_t* out_n_local);
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */
