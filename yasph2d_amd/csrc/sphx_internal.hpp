@@ -270,6 +270,7 @@ struct sphx_ctx {
     int run_ahead = 1;
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it
+    bool div_warm_fused = false;   // the latest neighbour build applied the divergence loop's warm start
     int host_loop = 0;        // SPHX_HOST_LOOP=1: the host judges every residual (round-1 behaviour; A/B runs)
     std::string prof_filter;  // sphx_profile_filter: only launches with this label are timed, every prof_every-th of them
     uint32_t prof_every = 1, prof_counter = 0;

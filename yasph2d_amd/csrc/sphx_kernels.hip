@@ -113,6 +113,7 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
     return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
 }
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
+__device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
 // NeighborRange (neighborhood_search.rs:269-273) of one particle + the list format of its workgroup in one word:
 // count_dynamic (7 bits) | count_total << 7 | entries of the workgroup's out-of-window table << 14 | wide << 31
@@ -975,11 +976,15 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 // its own nine cell ranges; k_neighbor_build2: the particles of a cell share one candidate list): static neighbours, densities and
 // alpha factors, list format and rows, statistics.  On entry tile[w][k][lane] (k < min(ct, STAGE_ROWS); further entries at their
 // 32-bit address in `list`) holds the accepted dynamic neighbours of the lane's particle as slots of the [N|B] arrays, ascending.
-// MODE 0: lists only; 1: + densities and alpha factors; 2: + the first compute_density_change of the divergence loop (DivArgs).
+// MODE 0: lists only; 1: + densities and alpha factors; 2: + the first compute_density_change of the divergence loop that follows
+// (when it starts without a warm start); 3: + that loop's warm start (when it starts with one) — DivArgs.
 struct DivArgs {
-    const float4* PV;   // sorted records: PV.zw = the velocities the divergence loop starts from
-    float4* PK;         // receives {pos, err * alpha, err} like k_compute_error<true>
-    float* warm_zero;   // warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
+    const float4* PV;   // MODE 2: sorted records, PV.zw = the velocities the divergence loop starts from
+    float4* PK;         // MODE 2: receives {pos, err * alpha, err} like k_compute_error<true>
+    float* warm_zero;   // MODE 2: warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
+    float4* PVw;        // MODE 3: PV.zw of the own particle is corrected in place (nobody reads velocities in this launch)
+    const float* warm;  // MODE 3: warm-start stiffness, slot-bound (dfsph.rs:316-344)
+    float lim;          // MODE 3: -0.5 rho0^2, dfsph.rs:356-358
 };
 __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restrict__ scal);
 template <int MODE>
@@ -987,9 +992,11 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                                         uint32_t* __restrict__ list, uint32_t* __restrict__ counts, uint32_t* __restrict__ remote,
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
-                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv) {
+                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
+                                        const float* swin, float warm_i) {
     constexpr bool FUSE = MODE >= 1;
     constexpr bool DIV = MODE == 2;
+    constexpr bool WARM = MODE == 3;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t* const mytile = &tile[w][0][lane];
     uint32_t cd = 0;
@@ -1040,10 +1047,13 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
         float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
         float delta = 0.0f;  // DIV: sum of (v_i - v_j) . grad W_ij, dfsph.rs:249-280, in the order k_compute_error<true> adds it
+        float wsx = 0.0f, wsy = 0.0f;                      // WARM: sum of (k_i + k_j) grad W_ij, dfsph.rs:316-344, as k_correct<true, false> adds it
+        const float ki = 0.5f * fmaxf(warm_i, dv.lim);  // dfsph.rs:356-358
         for (uint32_t k0 = 0; k0 < ct; k0 += 4) {
             uint32_t j[4];
             float2 rj[4];
             float2 vj[4];
+            float wj4[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) j[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
             if (k0 + 4u > STAGE_ROWS) {
@@ -1058,6 +1068,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 const uint32_t wj = j[u] - w0;
                 rj[u] = lds_read_f2(&win[min(wj, wlen)]);
                 if (DIV) vj[u] = lds_read_f2(&vwin[min(wj, wlen)]);
+                if (WARM) wj4[u] = lds_read_f1(&swin[min(wj, wlen)]);
                 far |= k0 + u < ct && wj >= wlen;
             }
             if (far) {
@@ -1069,6 +1080,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                             const float4 r = gat(dv.PV, j[u]);
                             vj[u] = make_float2(r.z, r.w);
                         }
+                        if (WARM) wj4[u] = gat(dv.warm, j[u] < soff ? j[u] : i);  // warm[] has no boundary tail; static entries do not use it
                     }
             }
 #pragma unroll
@@ -1092,6 +1104,13 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     const float t_delta = delta + (dvx * (sg * dx) + dvy * (sg * dy));
                     delta = on ? t_delta : delta;
                 }
+                if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
+                    const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
+                    const float sk = k0 + u < cd ? ki + kj : ki;
+                    const float t_x = wsx + sk * (sg * dx), t_y = wsy + sk * (sg * dy);
+                    wsx = on ? t_x : wsx;
+                    wsy = on ? t_y : wsy;
+                }
             }
         }
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
@@ -1103,6 +1122,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             dv.warm_zero[i] = 0.0f;
             div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
         }
+        if (WARM) ((float2*)dv.PVw)[2u * i + 1u] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
     }
     // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
     // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
@@ -1182,9 +1202,10 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (DIV) block_residual_add(div_err, scal);
 }
 
-// MODE 2 holds a window of velocities next to the window of positions: 25.6 KB of LDS, six workgroups per CU instead of eight
+// MODE 2 holds a window of velocities next to the window of positions (25.6 KB of LDS, six workgroups per CU instead of eight),
+// MODE 3 a window of warm-start values (22.5 KB, seven)
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 6 : 8, MODE == 2 ? 6 : 8))) void k_neighbor_build(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 6 : MODE == 3 ? 7 : 8, MODE == 2 ? 6 : MODE == 3 ? 7 : 8))) void k_neighbor_build(
     const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd, GridView gs, uint32_t* __restrict__ list,
     uint32_t* __restrict__ counts, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
@@ -1193,6 +1214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
     __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
     __shared__ float2 vwin[MODE == 2 ? 256 + 2 * WIN_HALO + 1 : 1];  // MODE 2: their velocities
+    __shared__ float swin[MODE == 3 ? 256 + 2 * WIN_HALO + 1 : 1];   // MODE 3: their warm-start stiffness
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
@@ -1215,6 +1237,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = vel[2u * (w0 + min(threadIdx.x + u * 256u, wlen - 1u))];
         vi = vel[2u * (live ? i : b0)];
     }
+    float sreg[MODE == 3 ? NWIN : 1];
+    float warm_i = 0.0f;
+    if (MODE == 3) {
+#pragma unroll
+        for (uint32_t u = 0; u < NWIN; ++u) sreg[u] = dv.warm[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
+        warm_i = dv.warm[live ? i : b0];
+        vi = ((const float2*)dv.PVw)[2u * (live ? i : b0) + 1u];
+    }
     uint32_t cx, cy;
     cell_of(K, pi, cx, cy);
     uint32_t slot[9], s[9], e[9];
@@ -1226,6 +1256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         if (threadIdx.x + u * 256u < wlen) {
             win[threadIdx.x + u * 256u] = wreg[u];
             if (MODE == 2) vwin[threadIdx.x + u * 256u] = vreg[u];
+            if (MODE == 3) swin[threadIdx.x + u * 256u] = sreg[u];
         }
     __syncthreads();
     SPHX_STAMP(0)
@@ -1289,7 +1320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv);
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
     SPHX_STAMP(7)
 }
 
@@ -1320,7 +1351,6 @@ __device__ __forceinline__ float4 lds_read_f4(const float4* p) {
     const u32x4_t v = *(lds_cu128*)p;
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
 // Everything a lane needs to walk its list, fetched with loads that depend on nothing but the lane's index: the kernels are
 // bound by the LENGTH of their dependent load chain (count -> index -> record -> next index ...: seven round trips in the
