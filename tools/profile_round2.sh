@@ -44,6 +44,8 @@ b 1M_fixed55 --steps 100 --fixed-iterations 5 5 --no-cpu-baseline
 b 1M_window3750 --steps 200 --skip-steps 3750 --no-cpu-baseline
 SPHX_HOST_LOOP=1 b 1M_hostloop_fixed55 --steps 100 --fixed-iterations 5 5 --no-cpu-baseline
 SPHX_RUN_AHEAD=0 b 1M_no_run_ahead --steps 100 --no-cpu-baseline
+SPHX_FUSE_DIV=0 b 1M_no_fused_divergence --steps 100 --no-cpu-baseline
+SPHX_FUSE_DIV=0 b 1M_window3750_no_fused_divergence --steps 200 --skip-steps 3750 --no-cpu-baseline
 b 1M_per_step_calls --steps 100 --per-step-calls --no-cpu-baseline
 b 1M_wcsph --steps 100 --solver wcsph --no-cpu-baseline
 b 64M --steps 5 --warmup 1 --particles 64000000 --no-cpu-baseline --no-roofline
