@@ -230,6 +230,9 @@ int sphx_sub_regrid(sphx_ctx* ctx, uint32_t* out_n_local);                 /* df
  * follows: the next sphx_sub_iteration(divergence = 1, first = 1) then skips that pass.  Only for a loop that starts WITHOUT a
  * warm start (sphx_sub_warmstart after this call is refused: the pass has already zeroed the warm-start values). */
 int sphx_sub_regrid_div(sphx_ctx* ctx, uint32_t* out_n_local);
+/* The other case: the divergence loop that follows starts WITH a warm start (dfsph.rs:354-360); the neighbour build applies it, and
+ * the sphx_sub_warmstart(divergence = 1) call that follows returns without launching anything. */
+int sphx_sub_regrid_warm(sphx_ctx* ctx, uint32_t* out_n_local);
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */

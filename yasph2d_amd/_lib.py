@@ -139,6 +139,7 @@ SIGNATURES = {
     "sphx_tile_count_kept": (_i, [_vp]),
     "sphx_sub_regrid": (_i, [_vp, C.POINTER(_u32)]),
     "sphx_sub_regrid_div": (_i, [_vp, C.POINTER(_u32)]),
+    "sphx_sub_regrid_warm": (_i, [_vp, C.POINTER(_u32)]),
     "sphx_sub_nonpressure": (_i, [_vp, _f, C.POINTER(_f)]),
     "sphx_sub_predict": (_i, [_vp, _f]),
     "sphx_sub_warmstart": (_i, [_vp, _i, _f]),

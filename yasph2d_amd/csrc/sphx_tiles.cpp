@@ -602,7 +602,8 @@ struct TileDriver {
     }
     // div_next: the divergence loop follows at once and starts without a warm start — the re-grid's neighbour build then also does that
     // loop's first compute_density_change (sphx_sub_regrid_div)
-    int refresh(bool div_next = false) {  // halo exchange (migration + fresh ghosts) followed by the re-grid of the local set
+    // warm_next: ... and starts WITH one: the build applies it (sphx_sub_regrid_warm; loop()'s sphx_sub_warmstart call is then a no-op)
+    int refresh(bool div_next = false, bool warm_next = false) {  // halo exchange (migration + fresh ghosts) followed by the re-grid of the local set
         std::vector<void*> send, recv;
         int rc = buffers(send, recv);
         if (rc) return rc;
@@ -633,7 +634,7 @@ struct TileDriver {
         }
         const void* cdummy = nullptr;
         TCHK(sphx_tile_apply_n(ctx, recv.empty() ? &cdummy : (const void* const*)recv.data(), (uint32_t)recv.size(), c));
-        TCHK(div_next ? sphx_sub_regrid_div(ctx, &n_local) : sphx_sub_regrid(ctx, &n_local));
+        TCHK(warm_next ? sphx_sub_regrid_warm(ctx, &n_local) : div_next ? sphx_sub_regrid_div(ctx, &n_local) : sphx_sub_regrid(ctx, &n_local));
         exchanges += 1;
         const double full = comm->world == 1 ? INF : (double)halo_now;
         valid = kvalid = full;  // rings (cells from the owned region) in which v* / kappa are exact
@@ -768,7 +769,7 @@ struct TileDriver {
             // rings of the interval that ends here: divergence loop of the previous step, non-pressure pass, this density loop, and
             // the one-ring offset of density/alpha (computed one traversal after the exchange)
             adapt_halo((int)(last_div_warm + 2 * last_div_iters + 1 + s.warmstart_density + 2 * s.density_iterations + 1));
-        rc = refresh(num_divergence_iters <= 1);  // migration + ghosts, dfsph.rs:512-518 (no warm start ahead <=> dfsph.rs:354 is false)
+        rc = refresh(num_divergence_iters <= 1, num_divergence_iters > 1);  // migration + ghosts, dfsph.rs:512-518 (warm start ahead <=> dfsph.rs:354)
         if (rc) return rc;
         rc = loop(true, dt, &s.divergence_iterations, &s.avg_divergence, &s.warmstart_divergence, &s.flags);  // dfsph.rs:521
         if (rc) return rc;
