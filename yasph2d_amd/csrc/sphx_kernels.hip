@@ -1617,9 +1617,8 @@ __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restri
 // one stripe, (2) every lane gets the cumulative sums
 __device__ __forceinline__ void residual_stripe_load(const DevScalars* __restrict__ scal, unsigned long long& hi, unsigned long long& lo) {
     const uint32_t lane = threadIdx.x & 63u;
-    // plain loads: the sums were left by the PREVIOUS kernel on the stream (nothing adds to them while this one runs), so every
-    // workgroup of an XCD can take them from that XCD's L2 — agent-scope loads go past the L2 to the fabric, and 4 000 workgroups
-    // asking it for the same 64 lines cost the density correction 2.5 us
+    // plain loads: the sums were left by the PREVIOUS kernel on the stream (nothing adds to them while this one runs), so the
+    // XCD's L2 can serve them; agent-scope loads would go past it to the fabric
     hi = lane < STRIPES ? scal->stripe[lane].res_hi : 0ull;
     lo = lane < STRIPES ? scal->stripe[lane].res_lo : 0ull;
 }
