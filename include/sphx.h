@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SPHX_ABI_VERSION 1
+#define SPHX_ABI_VERSION 2 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL */
 
 /* ---- status codes ---- */
 enum {
