@@ -224,7 +224,7 @@ struct sphx_ctx {
     // one array and the traversal loops need no dynamic/static branch.
     float2 *posA = nullptr, *posA2 = nullptr;  // [N|B] positions (compact copy for the candidate scan)
     float4 *PV = nullptr, *PV2 = nullptr;      // [N|B] {pos.x, pos.y, v.x, v.y}: v = velocity, after predict = predicted velocity
-    float4* PK = nullptr;                      // [N|B] {pos.x, pos.y, k = err*alpha, err}: written by compute_error, gathered by correct
+    float* kbuf = nullptr;                     // [N] k = err * alpha of the running solver iteration: written by compute_error, staged by correct
     float2* accel = nullptr;                   // [N]
     float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr;  // [N]
     float *kappa2 = nullptr, *stiff2 = nullptr;  // gather targets (tile mode only)

@@ -830,8 +830,7 @@ __global__ __launch_bounds__(256) void k_set_ids(uint32_t* __restrict__ pid, con
 
 // boundary tails of the [N|B] arrays: {bpos, 0, 0}
 __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ bpos, uint32_t nb, uint32_t soff, float2* __restrict__ posA,
-                                                     float2* __restrict__ posA2, float4* __restrict__ PV, float4* __restrict__ PV2,
-                                                     float4* __restrict__ PK) {
+                                                     float2* __restrict__ posA2, float4* __restrict__ PV, float4* __restrict__ PV2) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nb) return;
     const float2 p = bpos[j];
@@ -840,7 +839,6 @@ __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ b
     posA2[soff + j] = p;
     PV[soff + j] = r;
     PV2[soff + j] = r;
-    PK[soff + j] = r;
 }
 
 // In-kernel stamps (diagnostic builds only, -DSPHX_STAMPS: tools/ab_build.sh): cycles per phase, summed over wavefronts.  The
@@ -980,7 +978,7 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 // (when it starts without a warm start); 3: + that loop's warm start (when it starts with one) — DivArgs.
 struct DivArgs {
     const float4* PV;   // MODE 2: sorted records, PV.zw = the velocities the divergence loop starts from
-    float4* PK;         // MODE 2: receives {pos, err * alpha, err} like k_compute_error<true>
+    float* kbuf;        // MODE 2: receives err * alpha like k_compute_error<true>
     float* warm_zero;   // MODE 2: warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
     float4* PVw;        // MODE 3: PV.zw of the own particle is corrected in place (nobody reads velocities in this launch)
     const float* warm;  // MODE 3: warm-start stiffness, slot-bound (dfsph.rs:316-344)
@@ -1118,7 +1116,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         alpha[i] = alpha_i;
         if (DIV) {
             const float e = ct < 9u ? 0.0f : fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:261, :277-278
-            dv.PK[i] = make_float4(pi.x, pi.y, e * alpha_i, e);
+            dv.kbuf[i] = e * alpha_i;
             dv.warm_zero[i] = 0.0f;
             div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
         }
@@ -1837,7 +1835,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
 template <bool DIVERGENCE>
 __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
-                                                        NbView nb, float4* __restrict__ PK, float* __restrict__ warm_zero,
+                                                        NbView nb, float* __restrict__ kbuf, float* __restrict__ warm_zero,
                                                         DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la,
                                                         uint32_t* __restrict__ clear_hist, uint32_t clear_len) {
     // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
@@ -1882,7 +1880,7 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
                 e = fmaxf(K.rho0, e) - K.rho0;         // dfsph.rs:124
             }
         }
-        PK[i] = make_float4(pvi.x, pvi.y, e * alpha_i, e);
+        kbuf[i] = e * alpha_i;  // k = err * alpha: all the correction needs of a neighbour besides its position
         if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363, folded into the first iteration
         e_owned = tile_owns(K, pvi.x, pvi.y) ? e : 0.0f;
     }
@@ -1901,7 +1899,8 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // (LoopArgs): then the correction derives the verdict from the residual itself and only the last one counts.
 // hist == nullptr: plain correction.
 template <bool WARM, bool INV_DT>
-__global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __restrict__ PK, float* __restrict__ warm, uint32_t n,
+__global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float2* __restrict__ posA, const float* __restrict__ kbuf,
+                                                  float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
                                                   const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra) {
     float dt = WARM ? ca.dt : (la.enabled ? la.dt : ca.dt);
@@ -1939,28 +1938,30 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
             return;
         }
     }
-    // staged neighbour records: WARM: {pos, v*} (+ the warm-start value of the neighbour); else PK = {pos, k, err}
-    __shared__ float4 rec[STAGE_SLOTS];
-    __shared__ float warm_s[WARM ? STAGE_SLOTS : 1];
+    // staged per neighbour: its position and ONE scalar — WARM: its warm-start value; else k = err * alpha of this iteration
+    // (12 bytes a record; round 1 kept a packed {pos, k, err} float4 for one-gather-per-neighbour access, which the LDS staging made
+    // pointless: 16 bytes written per particle by compute_error, 16 staged per record here)
+    __shared__ float2 pos_s[STAGE_SLOTS];
+    __shared__ float w_s[STAGE_SLOTS];
+    const float* const wsrc = WARM ? (const float*)warm : kbuf;
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
     const float4 pvi = i < n ? PV[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float warm_i = i < n ? warm[i] : 0.0f;
     struct StageRec {
-        float4 r;
+        float2 p;
         float w;
     };
     nb_stage(
         h,
         [&](uint32_t g) {
-            // warm[] has no boundary tail; static entries do not use it
-            if (WARM) return StageRec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : 0u)};
-            return StageRec{gat(PK, g), 0.0f};
+            // warm[] / kbuf[] have no boundary tail; static entries do not use the scalar
+            return StageRec{gat(posA, g), gat(wsrc, g < soff ? g : 0u)};
         },
         [&](uint32_t slot, const StageRec& q) {
-            rec[slot] = q.r;
-            if (WARM) warm_s[slot] = q.w;
+            pos_s[slot] = q.p;
+            w_s[slot] = q.w;
         });
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
@@ -2005,23 +2006,20 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         const uint32_t cd = h.cd, ct = h.ct;
         float ki;
         float2 ri;
-        if (WARM) {
+        ri = make_float2(pvi.x, pvi.y);
+        if (WARM)
             ki = 0.5f * fmaxf(warm_i, lim);
-            ri = make_float2(pvi.x, pvi.y);
-        } else {
-            const float4 pki = h.wide ? PK[i] : lds_read_f4(&rec[i - h.lw0]);
-            ki = pki.z;
-            ri = make_float2(pki.x, pki.y);
-        }
+        else
+            ki = h.wide ? kbuf[i] : lds_read_f1(&w_s[i - h.lw0]);
         float dx = 0.0f, dy = 0.0f;
         struct Rec {
-            float4 r;
+            float2 p;
             float w;
         };
         auto consume = [&](const Rec& q, uint32_t k) {
-            const float2 g = wendland_grad(K, ri, make_float2(q.r.x, q.r.y));
+            const float2 g = wendland_grad(K, ri, q.p);
             // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
-            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.r.z;
+            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.w;
             const float s = k < cd ? ki + kj : ki;
             const float tx = dx + s * g.x, ty = dy + s * g.y;
             dx = k < ct ? tx : dx;
@@ -2029,15 +2027,8 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float4* __r
         };
         nb_traverse(
             h, ct,
-            [&](uint32_t slot) {
-                if (WARM) return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&warm_s[slot])};
-                return Rec{lds_read_f4(&rec[slot]), 0.0f};
-            },
-            [&](uint32_t g) {
-                // warm[] has no boundary tail; static entries do not use it
-                if (WARM) return Rec{gat((const float4*)PV, g), gat((const float*)warm, g < soff ? g : i)};
-                return Rec{gat(PK, g), 0.0f};
-            },
+            [&](uint32_t slot) { return Rec{lds_read_f2(&pos_s[slot]), lds_read_f1(&w_s[slot])}; },
+            [&](uint32_t g) { return Rec{gat(posA, g), gat(wsrc, g < soff ? g : i)}; },
             consume);
         float2 o;
         if (INV_DT) {
