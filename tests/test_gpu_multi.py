@@ -7,6 +7,7 @@ every owned particle must agree BIT FOR BIT, as must iteration counts, dt, the n
   * the built-in RCCL transport is brought up with one rank (RCCL refuses two ranks on the one GPU of this box — gpurun_out/
     r02_probe1/rccl_same_gpu.log: "Duplicate GPU detected" — so its multi-rank send/recv cannot be exercised here).
 """
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -209,3 +210,35 @@ def test_solver_trait_over_a_device_list():
     for _ in range(10):
         s.simulation_step(w, t, sync_world=True)
     assert w.num_dynamic_particles == n2 > len(pos) and np.isfinite(w.positions).all()
+
+
+def test_regrid_with_a_folded_divergence_pass_keeps_its_contract():
+    """sphx_sub_regrid_div / sphx_sub_regrid_warm: the re-grid's neighbour build does the first pass of the divergence loop that
+    follows.  What follows must be that loop: after _div the first divergence iteration (no warm start: the pass has zeroed the
+    warm-start values), after _warm the divergence warm start (a no-op then).  Anything else is refused, nothing is launched."""
+    L = _lib.lib()
+    m = MultiSolver(y.default_params(), devices=[0], halo=16)
+    pos, boundary = dam_break(1.0)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    t = y.TimeManager()
+    for _ in range(3):
+        m.step(t)
+    ctx = C.c_void_p(L.sphx_multi_tile_ctx(m.h, 0))
+    n = C.c_uint32()
+    s, owned = C.c_double(), C.c_uint64()
+    dt = np.float32(0.002)
+    assert L.sphx_sub_regrid_div(ctx, C.byref(n)) == 0
+    assert L.sphx_sub_warmstart(ctx, 1, dt) == _lib.ERR_NOT_READY          # a warm start cannot follow
+    assert L.sphx_sub_iteration(ctx, 0, dt, 1, C.byref(s), C.byref(owned)) == _lib.ERR_NOT_READY  # nor a density iteration
+    assert L.sphx_sub_regrid_div(ctx, C.byref(n)) == 0
+    assert L.sphx_sub_iteration(ctx, 1, dt, 1, C.byref(s), C.byref(owned)) == 0 and owned.value == n.value == len(pos)
+    a = s.value
+    assert L.sphx_sub_regrid(ctx, C.byref(n)) == 0
+    assert L.sphx_sub_iteration(ctx, 1, dt, 1, C.byref(s), C.byref(owned)) == 0
+    assert s.value >= 0 and np.isfinite(a)
+    assert L.sphx_sub_regrid_warm(ctx, C.byref(n)) == 0
+    assert L.sphx_sub_warmstart(ctx, 0, dt) == _lib.ERR_NOT_READY           # the DIVERGENCE loop's warm start was applied
+    assert L.sphx_sub_regrid_warm(ctx, C.byref(n)) == 0
+    assert L.sphx_sub_warmstart(ctx, 1, dt) == 0                            # accepted, nothing launched
+    assert L.sphx_sub_iteration(ctx, 1, dt, 1, C.byref(s), C.byref(owned)) == 0
