@@ -298,6 +298,12 @@ def main():
         lay = {"auto": ylib.LAYOUT_AUTO, "strips": ylib.LAYOUT_STRIPS, "grid": ylib.LAYOUT_GRID}[args.tiles]
         kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay, overlap_exchange=args.overlap_exchange)
         job = "bench" + os.environ.get("MASTER_PORT", "0")
+        if dist is not None:
+            # the shared-memory segment of the scalar all-reduce is found by name: a token chosen by rank 0 keeps a segment a crashed
+            # earlier run with the same port may have left behind from being opened by a rank that gets there before rank 0
+            tok = [os.urandom(4).hex() if rank == 0 else None]
+            dist.broadcast_object_list(tok, src=0)
+            job += "_" + tok[0]
         if dist is None:
             multi = MultiSolver(params, devices=[dev_index], **kw)  # --force-tiles: one tile, the tile code path
         else:
@@ -491,6 +497,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pos, boundary)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if multi is not None:  # tiles, their communicator and the shared-memory segment of the scalar all-reduce (rank 0 unlinks it)
+        comm_obj = getattr(multi, "_comm", None)
+        if dist is not None:
+            dist.barrier()
+        multi.close()
+        if comm_obj is not None and hasattr(comm_obj, "close"):
+            comm_obj.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
