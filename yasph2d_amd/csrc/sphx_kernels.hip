@@ -352,7 +352,8 @@ __device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t
 }
 __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in, uint2* __restrict__ out, uint32_t len,
                                                        unsigned long long* __restrict__ state, uint32_t epoch,
-                                                       DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total) {
+                                                       DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total, Mailbox* __restrict__ mb,
+                                                       uint32_t mb_seq) {
     const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * SCAN_TILE;
     uint32_t v[16];
@@ -420,6 +421,13 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     __syncthreads();
     run += excl_s;
     if (bid == gridDim.x - 1 && threadIdx.x == 0 && d_total) *d_total = excl_s + total;  // grand total = particles that got a cell
+    if (mb && bid == gridDim.x - 1) {
+        // tile path: the host wants that total (the tile's new local count) as early as possible — published from here instead of
+        // from a one-workgroup kernel of its own behind the scan (4.5 us of the stream per re-grid)
+        if (threadIdx.x == 0) __hip_atomic_store(&scal->sort_total, excl_s + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        publish_common(scal, mb, mb_seq);
+    }
     if (full) {
         uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
 #pragma unroll
