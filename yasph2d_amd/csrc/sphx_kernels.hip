@@ -993,6 +993,24 @@ struct DivArgs {
     float lim;          // MODE 3: -0.5 rho0^2, dfsph.rs:356-358
 };
 __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restrict__ scal);
+// LDS byte address of a __shared__ object / a 32-bit store to one: the candidate scan keeps the ADDRESS of its next list row in a
+// register and moves it by one row per accepted candidate (one add instead of a clamp, a shift-add and an index add per candidate)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_store_u32(uint32_t addr, uint32_t v) { *(lds_u32*)(uintptr_t)addr = v; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
+typedef __attribute__((address_space(3))) const f32x4_a8 lds_cf4a8;  // two consecutive float2 slots: one ds_read2_b64
+constexpr uint32_t WIN_SLOTS = 256 + 2 * WIN_HALO;
+constexpr uint32_t WIN_PAD = 4;  // a trip of the candidate scan reads four consecutive slots from a clamped base: pad slots behind the window
+constexpr uint32_t ROW_B = 256;  // bytes between two rows of a wavefront's staged list
+
+// A STAGED list entry (rows 0..STAGE_ROWS-1 of a wavefront, in LDS) is the neighbour's BYTE offset into the position window,
+// E = 8 (g - w0) for slot g of the [N|B] arrays ("negative" below the window; |E| < 2^31 since contexts hold < 2^28 slots): what
+// the candidate scan has in a register anyway, and what phase 2 addresses the window with.  Entries past the staged rows sit in
+// global memory as plain slots g (their 32-bit address in `list`).
+__device__ __forceinline__ uint32_t entry_slot(uint32_t E, uint32_t w0) { return w0 + (uint32_t)((int32_t)E >> 3); }
+
 template <int MODE>
 __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const GridView& gs,
                                         uint32_t* __restrict__ list, uint32_t* __restrict__ counts, uint32_t* __restrict__ remote,
@@ -1005,6 +1023,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     constexpr bool WARM = MODE == 3;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t* const mytile = &tile[w][0][lane];
+    const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
     uint32_t cd = 0;
     uint32_t slot[9], s[9], e[9];
     if (live) {
@@ -1015,7 +1034,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
         // (cx, cy pass through an opaque asm so that the compiler recomputes the nine local offsets here instead of keeping them alive
         // — spilled — across the whole candidate section for a block that most waves never enter)
-        // Staged / stored value of a static neighbour: its slot in the [N|B] record arrays, soff + j.
+        // A static neighbour's slot in the [N|B] record arrays is soff + j.
         uint32_t cxs = cx, cys = cy;
         asm volatile("" : "+v"(cxs), "+v"(cys));
         if (__any(maybe_static) && __any(slots9(gs, cxs, cys, slot))) {
@@ -1030,7 +1049,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
                     if (ct < MAX_NEIGHBORS) {
                         if (ct < STAGE_ROWS)
-                            mytile[ct * 64] = soff + j;
+                            mytile[ct * 64] = (soff + j - w0) * 8u;
                         else
                             list[ell_index(i, ct)] = soff + j;
                         ct += 1;
@@ -1048,77 +1067,89 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 #else
     if (FUSE && live) {
 #endif
-        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order,
-        // four neighbours per trip: their slots and positions are read together; the accumulation stays sequential
+        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order.
+        // The entries of a trip (four) and their records are read together, the accumulation stays sequential; the trip ends after two
+        // when no lane of the wavefront has a third (a wavefront whose longest list has 9 or 10 entries does 10 slots of arithmetic)
+        // (x and y components ride in packed instructions — v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations on both halves, the
+        // same roundings as the scalar forms)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
-        float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
+        float gss = 0.0f;
+        f32x2 gs = {0.0f, 0.0f};
         float delta = 0.0f;  // DIV: sum of (v_i - v_j) . grad W_ij, dfsph.rs:249-280, in the order k_compute_error<true> adds it
-        float wsx = 0.0f, wsy = 0.0f;                      // WARM: sum of (k_i + k_j) grad W_ij, dfsph.rs:316-344, as k_correct<true, false> adds it
+        f32x2 ws = {0.0f, 0.0f};                        // WARM: sum of (k_i + k_j) grad W_ij, dfsph.rs:316-344, as k_correct<true, false> adds it
         const float ki = 0.5f * fmaxf(warm_i, dv.lim);  // dfsph.rs:356-358
+        const f32x2 pi2 = {pi.x, pi.y}, vi2 = {vi.x, vi.y}, mass2 = {K.mass, K.mass};
         for (uint32_t k0 = 0; k0 < ct; k0 += 4) {
-            uint32_t j[4];
+            uint32_t E[4];  // window byte offsets (see entry_slot)
             float2 rj[4];
             float2 vj[4];
             float wj4[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) j[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
+            for (uint32_t u = 0; u < 4; ++u) E[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
             if (k0 + 4u > STAGE_ROWS) {
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u)
-                    if (k0 + u >= STAGE_ROWS && k0 + u < ct) j[u] = list[ell_index(i, k0 + u)];
+                    if (k0 + u >= STAGE_ROWS && k0 + u < ct) E[u] = (list[ell_index(i, k0 + u)] - w0) * 8u;
             }
-            // j = slot in the [N|B] arrays (static neighbours: soff + boundary index, never in the window)
             bool far = false;
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
-                const uint32_t wj = j[u] - w0;
-                rj[u] = lds_read_f2(&win[min(wj, wlen)]);
-                if (DIV) vj[u] = lds_read_f2(&vwin[min(wj, wlen)]);
-                if (WARM) wj4[u] = lds_read_f1(&swin[min(wj, wlen)]);
-                far |= k0 + u < ct && wj >= wlen;
+                const uint32_t wb = min(E[u], wlen_b);  // slot wlen: pad
+                rj[u] = lds_read_f2((const float2*)((const char*)win + wb));
+                if (DIV) vj[u] = lds_read_f2((const float2*)((const char*)vwin + wb));
+                if (WARM) wj4[u] = lds_read_f1((const float*)((const char*)swin + (wb >> 1)));
+                far |= k0 + u < ct && E[u] >= wlen_b;
             }
-            if (far) {
+            if (far) {  // static neighbours (soff + boundary index) are never in the window
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u)
-                    if (k0 + u < ct && j[u] - w0 >= wlen) {
-                        rj[u] = gat(posA, j[u]);
-                        if (DIV) {  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
-                            const float4 r = gat(dv.PV, j[u]);
-                            vj[u] = make_float2(r.z, r.w);
-                        }
-                        if (WARM) wj4[u] = gat(dv.warm, j[u] < soff ? j[u] : i);  // warm[] has no boundary tail; static entries do not use it
+                    if (k0 + u < ct && E[u] >= wlen_b) {
+                        const uint32_t gb = w0b + E[u];  // 8 g
+                        rj[u] = *(const float2*)((const char*)posA + gb);
+                        if (DIV) vj[u] = *(const float2*)((const char*)dv.PV + (gb * 2u + 8u));  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
+                        if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
                     }
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            auto add = [&](uint32_t u) {
                 const bool on = k0 + u < ct;
-                const float dx = rj[u].x - pi.x, dy = rj[u].y - pi.y;
-                const float r = sqrt_dist(dx * dx + dy * dy);
+                const f32x2 d = f32x2{rj[u].x, rj[u].y} - pi2;  // ri_to_rj
+                const f32x2 dd = d * d;
+                const float r = sqrt_dist(dd.x + dd.y);
                 const float q = fminf(r * K.w_hinv, 1.0f);
                 const float omq = 1.0f - q;
                 const float omq_sq = omq * omq;
                 const float t_rho = rho + (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
                 const float sg = K.w_ngrad * omq * omq * omq;
-                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-                const float t_gsx = gsx + gx, t_gsy = gsy + gy, t_gss = gss + (gx * gx + gy * gy);
+                const f32x2 sgd = f32x2{sg, sg} * d;  // wendland_grad(ri, rj)
+                const f32x2 g = sgd * mass2;
+                const f32x2 gg = g * g;
+                const f32x2 t_gs = gs + g;
+                const float t_gss = gss + (gg.x + gg.y);
                 rho = on ? t_rho : rho;
-                gsx = on ? t_gsx : gsx;
-                gsy = on ? t_gsy : gsy;
+                gs.x = on ? t_gs.x : gs.x;
+                gs.y = on ? t_gs.y : gs.y;
                 gss = on ? t_gss : gss;
-                if (DIV) {  // wendland_grad(ri, rj) = (sg dx, sg dy): the operations of k_compute_error<true>
-                    const float dvx = vi.x - vj[u].x, dvy = vi.y - vj[u].y;
-                    const float t_delta = delta + (dvx * (sg * dx) + dvy * (sg * dy));
+                if (DIV) {  // the operations of k_compute_error<true>
+                    const f32x2 dvg = (vi2 - f32x2{vj[u].x, vj[u].y}) * sgd;
+                    const float t_delta = delta + (dvg.x + dvg.y);
                     delta = on ? t_delta : delta;
                 }
                 if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
                     const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
                     const float sk = k0 + u < cd ? ki + kj : ki;
-                    const float t_x = wsx + sk * (sg * dx), t_y = wsy + sk * (sg * dy);
-                    wsx = on ? t_x : wsx;
-                    wsy = on ? t_y : wsy;
+                    const f32x2 t_ws = ws + f32x2{sk, sk} * sgd;
+                    ws.x = on ? t_ws.x : ws.x;
+                    ws.y = on ? t_ws.y : ws.y;
                 }
-            }
+            };
+            add(0);
+            add(1);
+            if (!__any(ct > k0 + 2u)) break;
+            add(2);
+            add(3);
         }
+        const float gsx = gs.x, gsy = gs.y, wsx = ws.x, wsy = ws.y;
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
         const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
         alpha[i] = alpha_i;
@@ -1131,7 +1162,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         if (WARM) ((float2*)dv.PVw)[2u * i + 1u] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
     }
     // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
-    // An entry is the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
+    // A list entry names the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
     // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
     // away in Morton order, or a boundary particle) gets the next free line r of this wavefront's quarter of the workgroup's
     // out-of-window table and is stored as LIST_WIN + w * WAVE_REMOTE + r.  Lines are handed out in a fixed order (row, lane).  A
@@ -1140,33 +1171,41 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     // fetches the first twelve entries of its particle with three coalesced loads that depend on nothing.
     const uint32_t lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     const uint32_t lwlen = min(b0 + 256u + LIST_HALO, n) - lw0;
+    const uint32_t wshift = w0 - lw0;  // staged entry -> slot of the list window: (E >> 3) + (w0 - lw0)
     const uint32_t cap = K.remote_cap / 4u;
     uint32_t m = min(ct, STAGE_ROWS);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+#ifdef SPHX_ABL_NOFORMAT  // (instruction-count experiments: tools/ab_build.sh)
+    m = 0;
+#endif
     const bool spill = __any(ct > STAGE_ROWS);
-    uint32_t* const rtab = remote + (size_t)xcd_bid() * REMOTE_CAP + w * WAVE_REMOTE;
-    char* const slice = (char*)(list + (size_t)(i >> 6) * 4096);
-    const unsigned long long below = (1ull << lane) - 1ull;
+    // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
+    uint32_t* const rtab = remote + ((size_t)xcd_bid() * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
+    char* const slice = (char*)(list + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     // optimistic single pass: 16-bit rows and table lines go out while the lines are counted; a wavefront that overflows its quarter
     // of the table (rare) rewrites its rows as 32-bit ones afterwards
     uint32_t run = 0;
     if (cap) {
-        uint32_t packed[2] = {0u, 0u};
-        for (uint32_t k = 0; k < m; ++k) {
-            const uint32_t g = lds_read_u32(&tile[w][k][lane]);
-            const bool rem = k < ct && g - lw0 >= lwlen;
-            const unsigned long long mask = __ballot(rem);
-            const uint32_t r = run + (uint32_t)__popcll(mask & below);
-            run += (uint32_t)__popcll(mask);
-            if (rem && r < WAVE_REMOTE) rtab[r] = g;
-            const uint32_t sl = (rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0) & 0xffffu;
-            const uint32_t q = k & 3u;
-            if (q == 0u) packed[0] = sl;
-            if (q == 1u) packed[0] |= sl << 16;
-            if (q == 2u) packed[1] = sl;
-            if (q == 3u) packed[1] |= sl << 16;
-            if (q == 3u || k + 1u == m) *(uint2*)(slice + (k >> 2) * 512u + lane * 8u) = make_uint2(packed[0], packed[1]);
+        // four rows per trip = one 8-byte word per lane (rows >= m of the last group hold don't-care values: traversals stop at the count)
+        const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
+        const uint32_t lane8 = lane * 8u;
+        const uint32_t* const trow = &tile[w][0][lane];
+        for (uint32_t k0 = 0; k0 < m; k0 += 4u) {
+            uint32_t sl[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t gl = (uint32_t)((int32_t)lds_read_u32(trow + (k0 + u) * 64u) >> 3) + wshift;  // g - lw0
+                const bool rem = k0 + u < ct && gl >= lwlen;
+                const unsigned long long mask = __ballot(rem);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, run));
+                run += (uint32_t)__popcll(mask);
+                if (rem && r < WAVE_REMOTE) rtab[r] = gl + lw0;
+                sl[u] = rem ? rbase + r : gl;
+            }
+            // the low halves of two registers in one instruction each
+            const uint32_t p0 = __builtin_amdgcn_perm(sl[1], sl[0], 0x05040100u), p1 = __builtin_amdgcn_perm(sl[3], sl[2], 0x05040100u);
+            *(uint2*)(slice + ((k0 >> 2) * 512u + lane8)) = make_uint2(p0, p1);
         }
     }
     uint32_t spill_rem = 0, spill_before = 0;
@@ -1182,7 +1221,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (wide) {
         // entries past the staged rows already sit at their 32-bit address
         const size_t row0 = (size_t)(i >> 6) * 64;
-        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = lds_read_u32(&tile[w][k][lane]);
+        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = entry_slot(lds_read_u32(&tile[w][k][lane]), w0);
     } else if (spill) {
         // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address, byte
         // 256 k + 4 lane); their 16-bit home, byte 128 (k & ~3) + 8 lane + 2 (k & 3), lies below every 32-bit row >= k, so
@@ -1217,10 +1256,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
-    __shared__ uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
-    __shared__ float2 win[256 + 2 * WIN_HALO + 1];    // positions of the sorted particles around this workgroup's 256 (+1: pad slot)
-    __shared__ float2 vwin[MODE == 2 ? 256 + 2 * WIN_HALO + 1 : 1];  // MODE 2: their velocities
-    __shared__ float swin[MODE == 3 ? 256 + 2 * WIN_HALO + 1 : 1];   // MODE 3: their warm-start stiffness
+    // (one object, the window first: at LDS offset 0 the four slots of a trip are one clamped base register + immediate offsets)
+    struct Smem {
+        float2 win[WIN_SLOTS + WIN_PAD];       // positions of the sorted particles around this workgroup's 256 (+ pad slots)
+        uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
+        float2 vwin[MODE == 2 ? WIN_SLOTS + WIN_PAD : 1];  // MODE 2: their velocities
+        float swin[MODE == 3 ? WIN_SLOTS + WIN_PAD : 1];   // MODE 3: their warm-start stiffness
+    };
+    __shared__ Smem sm;
+    float2* const win = sm.win;
+    uint32_t (*const tile)[STAGE_ROWS + 1][64] = sm.tile;
+    float2* const vwin = sm.vwin;
+    float* const swin = sm.swin;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
@@ -1231,7 +1278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     SPHX_STAMP_BEGIN()
     const bool live = i < n;
     const float2 pi = posA[live ? i : b0];  // own position straight from global memory: the cell look-ups below do not wait for the barrier
-    constexpr uint32_t NWIN = (256 + 2 * WIN_HALO + 255) / 256;
+    constexpr uint32_t NWIN = (WIN_SLOTS + 255) / 256;
     float2 wreg[NWIN];
 #pragma unroll
     for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
@@ -1264,40 +1311,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             if (MODE == 2) vwin[threadIdx.x + u * 256u] = vreg[u];
             if (MODE == 3) swin[threadIdx.x + u * 256u] = sreg[u];
         }
+    // pad slots: a candidate read past the window's end finds a NaN position (rejected) until the re-read from global memory replaces it
+    if (threadIdx.x < WIN_PAD) win[wlen + threadIdx.x] = make_float2(__uint_as_float(0x7FC00000u), 0.0f);
     __syncthreads();
     SPHX_STAMP(0)
     uint32_t ct = 0;
-    uint32_t* const mytile = &tile[w][0][lane];
-    const uint32_t wlen_b = wlen * 8u;
+    const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
     if (live) {
         // phase 1: filter
         SPHX_STAMP(1)
 #ifndef SPHX_ABL_NOLOOP
+        // the list row the next accepted candidate goes to, as an LDS byte address (row ct of this lane): it moves by one row per
+        // accepted candidate.  t_dump: the dump row (row STAGE_ROWS); t_fast: while no lane of the wavefront is past it, the four
+        // candidates of a trip land in staged rows (or, rejected, in the dump row) whatever is accepted: no clamp, no spill test.
+        const uint32_t t_base = lds_addr(&tile[w][0][lane]);
+        const uint32_t t_dump = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;
+        uint32_t ta = t_base;
+        const uint32_t far_lim = wlen_b > 24u ? wlen_b - 24u : 0u;  // a trip starting at or beyond this byte offset (or below the window) leaves the window
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
             // itself: an LDS round trip, five exec-mask branches and a vmcnt(0) wait per candidate.)  A cell holds ~3-4 particles, so
-            // a cell is usually one trip: four window reads in flight together, four distance tests, and an ORDERED branch-free
+            // a cell is usually one trip: four window slots in two reads, four distance tests, and an ORDERED branch-free
             // append: every lane writes all four candidates in order (see below).
-            // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28);
+            // * the loop runs on the candidate's BYTE offset into the window (ab = 8 (j - w0), "negative" for j < w0; n < 2^28), which
+            //   is also what is stored for an accepted candidate (entry_slot);
             // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
             // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
-            const uint32_t eb = (e[t] - w0) * 8u;
-            uint32_t ab = (s[t] - w0) * 8u;
+            const uint32_t eb = e[t] * 8u - w0b;
+            uint32_t ab = s[t] * 8u - w0b;
             while (ab != eb) {
-                const uint32_t left = (eb - ab) >> 3;  // >= 1
-                float2 pj[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) pj[u] = lds_read_f2((const float2*)((const char*)win + min(ab + 8u * u, wlen_b)));  // win[wlen]: pad slot
+                const uint32_t rem = eb - ab;  // bytes of candidates left in this cell (>= 8)
+                const char* const base = (const char*)win + min(ab, wlen_b);  // below or beyond the window: the pad slots
+                const f32x4 p01 = *(lds_cf4a8*)base, p23 = *(lds_cf4a8*)(base + 16);
+                float2 pj[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
 #ifndef SPHX_ABL_NOFALLBACK  // (timing experiments: tools/ab_build.sh)
-                if (ab >= wlen_b || ab + 24u >= wlen_b) {  // the first (ab "negative": j < w0) or the last of the four lies outside the window
+                if (ab >= far_lim) {
+                    // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL four from
+                    // global memory (one address, four loads with immediate offsets; what the window holds is the same data, and the
+                    // slots past the run's end are never accepted — posA is allocated four slots longer than the particle arrays)
+                    const float2* const gp = (const float2*)((const char*)posA + (w0b + ab));
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)
-                        if (ab + 8u * u >= wlen_b && u < left) pj[u] = gat(posA, w0 + (uint32_t)((int32_t)(ab + 8u * u) >> 3));
+                    for (uint32_t u = 0; u < 4; ++u) pj[u] = gp[u];
                 }
 #endif
-                uint32_t c[5];
-                c[0] = ct;
                 bool acc[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
@@ -1306,23 +1363,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
                     const f32x2 q = d * d;
                     const float d2 = q.x + q.y;
-                    acc[u] = u < left && d2 <= K.radius_sq && d2 > 1.0e-10f;
-                    c[u + 1] = c[u] + (acc[u] ? 1u : 0u);
+                    acc[u] = (u == 0u || rem > 8u * u) && d2 <= K.radius_sq && d2 > 1.0e-10f;  // (rem >= 8 inside the loop)
                 }
-                const uint32_t j0 = w0 + (uint32_t)((int32_t)ab >> 3);
-                // every candidate is WRITTEN to the row the running count points at; a rejected one is overwritten by the next accepted
-                // one (the count has not moved), an accepted one is safe (the count moves past it).  Row STAGE_ROWS absorbs the rest.
+                // every candidate is WRITTEN to the row the running address points at; a rejected one is overwritten by the next accepted
+                // one (the address has not moved), an accepted one is safe (the address moves past it).  The dump row absorbs the rest.
+                uint32_t a[5];
+                a[0] = ta;
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) mytile[min(c[u], STAGE_ROWS) * 64u] = j0 + u;
-                if (c[4] > STAGE_ROWS) {  // rare: rows past the staged ones live in global memory (32-bit, at their wide address)
+                for (uint32_t u = 0; u < 4; ++u) a[u + 1] = a[u] + (acc[u] ? ROW_B : 0u);
+                if (!__any(ta > t_fast)) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)
-                        if (acc[u] && c[u] >= STAGE_ROWS && c[u] < MAX_NEIGHBORS) list[ell_index(i, c[u])] = j0 + u;
+                    for (uint32_t u = 0; u < 4; ++u) lds_store_u32(a[u], ab + 8u * u);
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) lds_store_u32(min(a[u], t_dump), ab + 8u * u);
+                    if (a[4] > t_dump) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t row = (a[u] - t_base) / ROW_B;
+                            if (acc[u] && row >= STAGE_ROWS && row < MAX_NEIGHBORS) list[ell_index(i, row)] = entry_slot(ab + 8u * u, w0);
+                        }
+                    }
                 }
-                ct = c[4];
-                ab += min(left, 4u) * 8u;
+                ta = a[4];
+                ab = (uint32_t)min((int32_t)(ab + 32u), (int32_t)eb);
             }
         }
+        ct = (ta - t_base) / ROW_B;
 #endif
     }
     SPHX_STAMP(2)
