@@ -203,8 +203,8 @@ int sphx_get_constants(const sphx_ctx* ctx, float* out6);
 /* ---- spatial tiles (multi-GPU) ------------------------------------------------------------------------------
  * The reference has no distributed path; these entry points are the device half of the build's own domain decomposition.
  * One context = one tile: the cells with cell_lo <= c < cell_hi along `axis` (0 = x, 1 = y) are OWNED, a halo of `halo_cells`
- * cells on each side holds copies (ghosts) of the neighbours' particles.  The host driver (yasph2d_amd/tiles.py; in a Rust host
- * this would sit inside the Solver impl) runs the sub-steps below in the order of dfsph.rs:414-525, all-reduces the three
+ * cells on each side holds copies (ghosts) of the neighbours' particles.  The host driver (sphx_multi_* below — csrc/sphx_tiles.cpp; tests/tiles_reference.py is its Python
+ * reference implementation) runs the sub-steps below in the order of dfsph.rs:414-525, all-reduces the three
  * per-step scalars, and once per step — between advect and re-grid — exchanges 32-byte halo records with the two spatial
  * neighbours (RCCL send/recv on the device buffers).  With a halo wider than the number of neighbour traversals between two
  * exchanges, ghost values are recomputed locally instead of being exchanged per sub-step.

@@ -1333,7 +1333,7 @@ uint32_t orc_get_neighbor_flags(OrcSim* s) { return s->world.neighborhood.neighb
 
 
 // ---- sub-step API for the spatial-tile tests (tests/tile_oracle_backend.py) -------------------------------------------------
-// The product's multi-GPU driver (yasph2d_amd/tiles.py) is backend-agnostic; the CPU tests run it over this oracle with gloo.
+// The reference implementation of the multi-GPU tile loop (tests/tiles_reference.py) is backend-agnostic; the CPU tests run it over this oracle with gloo.
 // A tile holds owned + ghost particles in ONE local array; reductions only count particles whose cell coordinate along
 // `axis` lies in [lo, hi).  In tile mode the warm-start arrays travel with their particle (they cannot stay slot-bound
 // across tiles), everything else is the reference's per-particle arithmetic, unchanged.

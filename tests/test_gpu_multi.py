@@ -1,5 +1,5 @@
 """sphx_multi — the tile step loop inside libsphx (csrc/sphx_tiles.cpp) — against the reference implementation of the same loop:
-yasph2d_amd/tiles.py driving the CPU oracle (tests/tile_oracle_backend.py).  Same cuts, same halo rules, same re-partitioning:
+tests/tiles_reference.py driving the CPU oracle (tests/tile_oracle_backend.py).  Same cuts, same halo rules, same re-partitioning:
 every owned particle must agree BIT FOR BIT, as must iteration counts, dt, the number of halo exchanges and the final cuts.
 
   * all tiles in one process (sphx_multi_create: one host thread + HIP stream per tile, peer copies ordered by events);
@@ -20,7 +20,7 @@ from util import assert_bits_equal, dam_break
 import yasph2d_amd as y
 from yasph2d_amd import _lib
 from yasph2d_amd.multi import MultiSolver
-from yasph2d_amd.tiles import cell_coord, quantile_cuts
+from tiles_reference import cell_coord, quantile_cuts
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))

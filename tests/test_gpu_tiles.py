@@ -7,7 +7,7 @@ from test_tiles_cpu import merge_owned, run_tiles_threaded
 from util import assert_bits_equal, dam_break
 
 import yasph2d_amd as y
-from yasph2d_amd.tiles import GpuTileBackend
+from tiles_reference import GpuTileBackend
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +60,7 @@ def test_gpu_tiles_rebalance_bit_exact_vs_oracle_tiles():
     """Lopsided initial cut + re-partition every 2 steps (cuts move while particles migrate; boundary re-clip margin active):
     the HIP tiles follow the oracle tiles bit for bit, cut for cut."""
     from tile_oracle_backend import OracleTileBackend
-    from yasph2d_amd.tiles import cell_coord
+    from tiles_reference import cell_coord
 
     pos, boundary = dam_break(1.0)
     c = cell_coord(pos, 1)
@@ -160,7 +160,7 @@ def test_gpu_tile_that_owns_nothing():
     """A tile whose rectangle holds no fluid at all (all particles on the other side of the cut): it reports 0 owned particles to
     the residual average every iteration — not a stale count — and the other tile reproduces the oracle tiles bit for bit."""
     from tile_oracle_backend import OracleTileBackend
-    from yasph2d_amd.tiles import cell_coord
+    from tiles_reference import cell_coord
 
     pos, boundary = dam_break(1.0)
     c = cell_coord(pos, 0)
@@ -180,7 +180,7 @@ def test_gpu_empty_tile_receives_its_first_particles():
     """The dam break spreads into a tile that started with nothing: the first records it receives must get cells (its directory is
     empty until then) and stay — owned counts and every particle agree with the oracle tiles bit for bit."""
     from tile_oracle_backend import OracleTileBackend
-    from yasph2d_amd.tiles import cell_coord
+    from tiles_reference import cell_coord
 
     pos, boundary = dam_break(1.0)
     c = cell_coord(pos, 0)

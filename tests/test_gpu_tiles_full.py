@@ -25,7 +25,7 @@ import pytest
 from util import dam_break
 
 import yasph2d_amd as y
-from yasph2d_amd.tiles import GpuTileBackend, GridLayout, StripLayout, ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
+from tiles_reference import GpuTileBackend, GridLayout, StripLayout, ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
 
 pytestmark = pytest.mark.gpu
 

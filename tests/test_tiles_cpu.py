@@ -1,4 +1,4 @@
-"""Multi-GPU path on CPU: the tile driver (yasph2d_amd/tiles.py — partitioning, halo records, migration, ring budget,
+"""Multi-GPU path on CPU: the tile driver (tests/tiles_reference.py — partitioning, halo records, migration, ring budget,
 collectives) runs over the oracle backend with world_size-2 gloo processes and with in-process thread ranks, and must
 reproduce the single-domain oracle run particle by particle (by id)."""
 import os
@@ -11,7 +11,7 @@ from util import dam_break
 
 import yasph2d_amd as y
 from oracle.oracle import Oracle
-from yasph2d_amd.tiles import GridLayout, StripLayout, ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
+from tiles_reference import GridLayout, StripLayout, ThreadComm, TiledDFSPH, cell_coord, quantile_cuts
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -116,7 +116,7 @@ def test_tiles_with_impact_migration_and_long_loops():
 
 
 def test_rebalance_cuts_rule():
-    from yasph2d_amd.tiles import rebalance_cuts
+    from tiles_reference import rebalance_cuts
 
     cuts = [0, 5000, 5100, 5200, 65536]
     assert rebalance_cuts(cuts, [100, 100, 100, 100], 8, 10.0, 2) == cuts                     # balanced: untouched
@@ -187,7 +187,7 @@ def test_adaptive_halo_follows_the_ring_budget():
 
 
 def test_grid_layout_geometry():
-    from yasph2d_amd.tiles import in_rect, rects_touch
+    from tiles_reference import in_rect, rects_touch
 
     pos, _ = dam_break(2.0)
     lay = GridLayout.quantile(pos, 2, 2)
@@ -248,7 +248,7 @@ def test_tiles_2x2_impact_migration_rebalance():
 
 
 def in_rect_one(p, rect):
-    from yasph2d_amd.tiles import in_rect
+    from tiles_reference import in_rect
 
     q = np.asarray(p, np.float32).reshape(1, 2)
     return bool(in_rect(cell_coord(q, 0), cell_coord(q, 1), rect)[0])
@@ -260,7 +260,7 @@ import numpy as np
 sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
 import torch, torch.distributed as dist
 import yasph2d_amd as y
-from yasph2d_amd.tiles import ShmComm, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
+from tiles_reference import ShmComm, TiledDFSPH, TorchComm, cell_coord, quantile_cuts
 from tile_oracle_backend import OracleTileBackend
 from util import dam_break
 dist.init_process_group("gloo")
@@ -354,7 +354,7 @@ def test_shm_allreduce_four_processes():
 def test_rebalance_cuts_invariants_random():
     """Whatever the loads: cuts stay strictly increasing with the outer ones fixed, no cut moves further than max_shift, interior
     tiles keep two halo widths (+2), and the function is a pure function of its inputs."""
-    from yasph2d_amd.tiles import rebalance_cuts
+    from tiles_reference import rebalance_cuts
 
     rng = np.random.default_rng(11)
     for _ in range(2000):
@@ -373,7 +373,7 @@ def test_rebalance_cuts_invariants_random():
 
 
 def test_grid_layout_partitions_random_clouds():
-    from yasph2d_amd.tiles import in_rect
+    from tiles_reference import in_rect
 
     rng = np.random.default_rng(12)
     for _ in range(20):

@@ -1,4 +1,4 @@
-"""CPU backend of yasph2d_amd.tiles.TiledDFSPH for the tests: the sub-steps are executed by the oracle, the halo
+"""CPU backend of tests/tiles_reference.TiledDFSPH for the tests: the sub-steps are executed by the oracle, the halo
 pack/apply logic is restated in numpy (same selection rules and the same record order as the HIP kernels k_tile_*)."""
 import ctypes as C
 
@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle.oracle import Oracle
-from yasph2d_amd.tiles import HALO_DTYPE, HALO_RECORD_BYTES, cell_coord, in_rect
+from tiles_reference import HALO_DTYPE, HALO_RECORD_BYTES, cell_coord, in_rect
 
 OWNED = np.uint32(0x80000000)
 

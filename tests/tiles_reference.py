@@ -1,4 +1,9 @@
-"""Spatial-tile (multi-GPU) driver of the DFSPH step — SURVEY.md §8(e), DESIGN.md §7.
+"""TEST INFRASTRUCTURE: the Python reference implementation of the spatial-tile driver.
+
+The product's tile step loop lives inside libsphx (`sphx_multi_*`, yasph2d_amd/csrc/sphx_tiles.cpp); this module restates the same
+loop above the sub-step C ABI (`sphx_sub_*` / `sphx_tile_*`) so that the tests can check the C++ loop against it bit for bit
+(tests/test_gpu_multi.py), run it over an oracle-backed backend on CPU (tests/test_tiles_cpu.py, tests/tile_oracle_backend.py)
+and over a single GPU at the BASELINE sizes (tests/test_gpu_tiles_full.py).  Nothing under yasph2d_amd/ imports it.
 
 The reference (yasph2d) has no distributed path.  The domain is cut at cell boundaries into rectangles — strips along one axis
 (`StripLayout`, the 8-GPU layout) or columns that are cut again across (`GridLayout`, 2x2 on 4 GPUs); rank r OWNS the particles
@@ -26,8 +31,8 @@ import threading
 
 import numpy as np
 
-from . import _lib
-from ._lib import SphxError
+from yasph2d_amd import _lib
+from yasph2d_amd._lib import SphxError
 
 HALO_RECORD_BYTES = 32
 HALO_DTYPE = np.dtype([("pv", np.float32, 4), ("id", np.uint32), ("kappa", np.float32), ("stiff", np.float32), ("pad", np.uint32)])
@@ -602,7 +607,7 @@ class TiledDFSPH:
 
     def step(self, timer):
         """One simulation_step; `timer` mirrors TimeManager (yasph2d_amd.TimeManager); identical on every rank."""
-        from . import duration_as_secs_f32
+        from yasph2d_amd import duration_as_secs_f32
 
         dt_prev = timer.simulation_step()
         self._need(min(self._avalid, self._valid) - 1)

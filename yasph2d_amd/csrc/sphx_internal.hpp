@@ -27,10 +27,10 @@ constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 thre
 #define SPHX_STAGE_ROWS 12
 #endif
 #ifndef SPHX_WIN_HALO
-#define SPHX_WIN_HALO 256
+#define SPHX_WIN_HALO 128
 #endif
 constexpr uint32_t STAGE_ROWS = SPHX_STAGE_ROWS;     // neighbour rows staged in LDS per wave before the coalesced row store
-constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions of [block_first - 256, block_last + 256] are staged in LDS
+constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions of [block_first - 128, block_last + 128] are staged in LDS (256: same speed at 6 instead of 7 workgroups per CU in the form that also stages velocities)
 #ifndef SPHX_LIST_HALO
 #define SPHX_LIST_HALO 128
 #endif

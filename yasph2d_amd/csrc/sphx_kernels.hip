@@ -1247,10 +1247,16 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (DIV) block_residual_add(div_err, scal);
 }
 
-// MODE 2 holds a window of velocities next to the window of positions (25.6 KB of LDS, six workgroups per CU instead of eight),
-// MODE 3 a window of warm-start values (22.5 KB, seven)
+// MODE 2 holds a window of velocities next to the window of positions (21.1 KB of LDS, seven workgroups per CU instead of eight),
+// MODE 3 a window of warm-start values (19.1 KB, eight)
+#ifndef SPHX_NB_WAVES_M2
+#define SPHX_NB_WAVES_M2 7
+#endif
+#ifndef SPHX_NB_WAVES_M3
+#define SPHX_NB_WAVES_M3 8
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 6 : MODE == 3 ? 7 : 8, MODE == 2 ? 6 : MODE == 3 ? 7 : 8))) void k_neighbor_build(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8, MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8))) void k_neighbor_build(
     const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd, GridView gs, uint32_t* __restrict__ list,
     uint32_t* __restrict__ counts, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {

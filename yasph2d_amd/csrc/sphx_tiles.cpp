@@ -13,7 +13,7 @@
 //                              no link dependency on it), the scalars through the shared-memory all-reduce of sphx_shm_*; or
 //                              through a communicator supplied by the caller (sphx_comm_ops: the tests use torch.distributed/gloo).
 // The step loop itself (ring budget of the ghost band, adaptive band, re-partitioning, extra exchanges for long solver loops) is the
-// one of yasph2d_amd/tiles.py, statement for statement — that Python driver stays as the reference implementation the tests
+// one of tests/tiles_reference.py, statement for statement — that Python driver stays as the reference implementation the tests
 // run over the CPU oracle; the HIP tiles driven from here must match it bit for bit (tests/test_gpu_multi.py).
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
