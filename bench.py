@@ -29,14 +29,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): the practical ceiling of a streaming kernel
 
 
-def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5):
+def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
     """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 16-bit
     list format of this build — every list-consuming traversal moves the count word (4), 2*kbar of entries and 4*rbar of out-of-window
-    table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists."""
+    table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
+    folded: list traversals per step that the neighbour build does while it still holds the list in registers (the divergence loop's
+    first compute_density_change, or its warm start: SPHX_FUSE_DIV) — their list read does not happen and is not counted."""
+    lst = (4 + 2 * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     if compressed:
-        save = (8 + 4 * kbar) - (4 + 2 * kbar + 4 * rbar + 4.0 / 256)  # per traversal
-        return 252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)
-    return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar)
+        save = (8 + 4 * kbar) - lst  # per traversal
+        return (252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)
+                - folded * lst)
+    return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar) - folded * lst
 
 
 def cpu_model():
@@ -49,19 +53,24 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
-    """The oracle's OpenMP build (the reference's Rayon loops restated; 'port') timed on this host's cores, threads pinned
-    (OMP_PROC_BIND=close, OMP_PLACES=cores: without pinning the figure swung 1.9-3.5 M particle-steps/s between runs in round 1)."""
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    from oracle.oracle import Oracle, lib
-
-    L = lib(omp=True)
-    cores = L.orc_get_max_threads()
+CPU_BASELINE_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import yasph2d_amd as y            # host-side scene generator only (no GPU call)
+from oracle.oracle import Oracle, lib
+scale, budget_s, max_steps = float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+w = y.FluidParticleWorld()
+w.reset_fluid(scale)
+pos, boundary = np.array(w.positions), np.array(w.boundary_particles)
+L = lib(omp=True)
+out = {"threads": L.orc_get_max_threads(), "omp_proc_bind": L.orc_get_proc_bind(), "omp_num_places": L.orc_get_num_places(), "n": len(pos)}
+for name, allpar in (("port", 0), ("all_parallel", 1)):
+    L.orc_set_all_parallel(allpar)
     o = Oracle(omp=True)
     o.set_boundary(boundary)
     o.set_particles(pos)
-    o.dfsph_step()  # includes the warm-up block, like the GPU warm-up steps
+    o.dfsph_step()                 # includes the warm-up block, like the GPU warm-up steps; first touch of the pooled vectors
     t0 = time.perf_counter()
     steps = 0
     while steps < max_steps:
@@ -70,16 +79,52 @@ def cpu_baseline(pos, boundary, budget_s=12.0, max_steps=20):
         if time.perf_counter() - t0 > budget_s:
             break
     el = time.perf_counter() - t0
+    out[name] = {"value": len(pos) * steps / el, "steps": steps, "seconds": el}
+    del o
+print("CPUBASE " + json.dumps(out))
+"""
+
+
+def cpu_baseline(scale, budget_s=8.0, max_steps=20):
+    """The oracle's OpenMP build (the reference's Rayon loops restated; 'port') timed on this host's cores, in a FRESH child process
+    whose environment pins the threads before any OpenMP runtime exists (setting OMP_PROC_BIND inside this process came too late:
+    `import torch` had already initialised the libgomp the oracle binds to — round-2 advisor finding).  Two variants: the
+    reference-faithful one (`value`: rayon loops parallel, reference-serial loops serial) and `all_parallel` (every loop
+    that carries no order runs in parallel).  What the runtime really did with the threads is reported from the library."""
+    import subprocess
+
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    p = subprocess.run([sys.executable, "-c", CPU_BASELINE_CHILD, ROOT, repr(scale), repr(budget_s), str(max_steps)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=600)
+    line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("CPUBASE ")]
+    if p.returncode != 0 or not line:
+        return {"value": None, "unit": "particle-steps/s", "cores": None, "kind": "port", "error": p.stderr.decode(errors="replace")[-400:]}
+    r = json.loads(line[-1][8:])
+    bind = {0: "false", 1: "true", 2: "master", 3: "close", 4: "spread"}.get(r["omp_proc_bind"], str(r["omp_proc_bind"]))
     return {
-        "value": len(pos) * steps / el,
+        "value": r["port"]["value"],
         "unit": "particle-steps/s",
-        "cores": cores,
+        "cores": r["threads"],
         "kind": "port",
         "cpu": cpu_model(),
-        "threads": "OpenMP, OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
-        "sample": f"{steps} DFSPH steps of the same {len(pos)}-particle dam-break after 1 warm-up step, "
-                  f"C++/OpenMP restatement of yasph2d's Rayon path (not the Rust binary), {el:.1f} s",
+        "all_parallel": {"value": r["all_parallel"]["value"], "unit": "particle-steps/s", "cores": r["threads"],
+                         "what": "the same restatement with the loops the reference leaves serial (cell indices, apply_sorting, max-velocity scan, "
+                                 "velocity prediction, warm-start clamps) also in parallel — SURVEY 8(d)'s optional variant",
+                         "sample": f"{r['all_parallel']['steps']} steps, {r['all_parallel']['seconds']:.1f} s"},
+        "threads": f"OpenMP in a fresh child process: omp_get_max_threads() = {r['threads']}, omp_get_proc_bind() = {bind}, "
+                   f"omp_get_num_places() = {r['omp_num_places']} (environment of the child: OMP_PROC_BIND=close OMP_PLACES=cores)",
+        "sample": f"{r['port']['steps']} DFSPH steps of the same {r['n']}-particle dam-break after 1 warm-up step, C++/OpenMP restatement of "
+                  f"yasph2d's Rayon path (not the Rust binary; per-step vectors pooled like scratch_buffer.rs), {r['port']['seconds']:.1f} s",
     }
+
+
+def dry_workload(per_gpu, world):
+    """The workload string of a run without building the scene (add_fluid_rect, fluidparticleworld.rs:140-166: 90 particles per metre)."""
+    sc = float(np.sqrt(per_gpu * world / 4050.0))
+    n = int(np.float32(0.5 * sc) * np.float32(90.0)) * int(np.float32(1.0 * sc) * np.float32(90.0))
+    name = {4: " = BASELINE configs[3] (64 M, 2x2 tiles)", 8: " = BASELINE configs[4] (128 M, 8 strips)"}.get(world, "") if abs(per_gpu - 16_000_000) < 300_000 else ""
+    return f"DFSPH 2D dam-break (main.rs:177-196 scene x{sc:.2f}), ~{n} fluid particles in total (~{n // world} per GPU) on {world} GPU(s){name}"
 
 
 def launch_ranks(args, argv):
@@ -124,7 +169,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--skip-steps", type=int, default=0,
                     help="untimed steps before the warm-up (SURVEY 8(d): a second window after 2000 steps = the violent phase, high Id/Iv)")
-    ap.add_argument("--particles", type=int, default=1_000_000, help="target fluid particles per GPU (configs[1] = 1M)")
+    ap.add_argument("--particles", type=int, default=None,
+                    help="target fluid particles per GPU; default: 1 M on one GPU (BASELINE configs[1]), 16 M per GPU on several (4 GPUs = configs[3], "
+                         "64 M on 2x2 tiles; 8 GPUs = configs[4], 128 M on 8 strips)")
+    ap.add_argument("--no-also", action="store_true", help="one GPU, default workload: skip the two further windows of the line's `also` list "
+                                                           "(16 M from t=0; 1 M after 3750 steps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="widest ghost halo in cells (multi-GPU); the band in use adapts to the ring budget")
     ap.add_argument("--fixed-halo", action="store_true", help="always exchange the full --halo band")
@@ -161,6 +210,13 @@ def main():
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    default_workload = args.particles is None
+    if args.particles is None:
+        args.particles = 1_000_000 if args.gpus == 1 else 16_000_000
+    # the further windows ride on the plain `python bench.py [--steps K --warmup W]` run only (what the driver starts)
+    args.also = (default_workload and not args.no_also and args.gpus == 1 and args.solver == "dfsph" and not args.skip_steps
+                 and not any(args.fixed_iterations) and args.tolerance_scale == 1.0 and not args.force_tiles and not args.lists_32bit
+                 and not args.no_roofline and not args.dry_run)
     launched = "RANK" in os.environ
     if args.gpus > 1 and not launched:
         sys.exit(launch_ranks(args, sys.argv[1:]))
@@ -200,7 +256,8 @@ def main():
                                              "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                                              "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                                              "dtype": "f32", "data": "none (dry run of the rank launcher)",
-                                             "config": {"workload": "dry run: no compute"}}) + "\n").encode())
+                                             "config": {"workload": "dry run: no compute; would run " + dry_workload(args.particles, world),
+                                                        "particles_per_gpu": args.particles}}) + "\n").encode())
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -222,28 +279,23 @@ def main():
 
     import yasph2d_amd as y
 
-    # weak scaling: the global scene holds `particles` per GPU
-    scale = float(np.sqrt(args.particles * world / 4050.0))
-    w = y.FluidParticleWorld()
-    w.reset_fluid(scale)
-    pos, boundary = w.positions, w.boundary_particles
-    n_global = len(pos)
-    diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
-    timer = y.TimeManager(cfl_factor=0.2) if args.solver == "wcsph" else y.TimeManager()
-    params = y.default_params(device=dev_index, fixed_iterations=tuple(args.fixed_iterations))
-    if args.tolerance_scale != 1.0:
-        params.max_avg_density_error = float(np.float32(params.max_avg_density_error) * np.float32(args.tolerance_scale))
-        params.max_divergence_error = float(np.float32(params.max_divergence_error) * np.float32(args.tolerance_scale))
-    if args.lists_32bit:
-        params.list_span_limit = y.LISTS_32BIT
-    if args.solver == "wcsph" and (world > 1 or args.force_tiles):
-        raise SystemExit("--solver wcsph runs on one GPU")
-    if args.prewarm_ms > 0:
+    state = {"prewarmed": False}
+
+    def scene_of(particles_total):
+        scale = float(np.sqrt(particles_total / 4050.0))
+        w = y.FluidParticleWorld()
+        w.reset_fluid(scale)
+        return scale, w
+
+    def prewarm(particles):
         # Clock / page warm-up on a SCRATCH context (its own small scene, destroyed before the measured one exists): a fresh box runs
         # its first few hundred milliseconds of kernels at lower clocks, and W = 5 warm-up steps are 1 ms.  The measured context still
         # does exactly --warmup untimed and --steps timed steps from t = 0.
-        sw = y.FluidParticleWorld()
-        sw.reset_fluid(float(np.sqrt(min(args.particles, 1_000_000) / 4050.0)))
+        if args.prewarm_ms <= 0 or state["prewarmed"]:
+            return
+        state["prewarmed"] = True
+        _, sw = scene_of(min(particles, 1_000_000))
+        sd = np.float32(2.0) * np.float32(sw.properties()["particle_radius"])
         sctx = y.SphxContext(y.default_params(device=dev_index))
         sctx.set_boundary(sw.boundary_particles)
         sctx.upload(sw.positions)
@@ -251,17 +303,150 @@ def main():
         t_end = time.perf_counter() + args.prewarm_ms * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(20):
-                v = sctx.step_begin(stimer.simulation_step(), stimer.law(diam))
-                sctx.step_finish(y.duration_as_secs_f32(stimer.update_simulation_step(diam, v)))
+                v = sctx.step_begin(stimer.simulation_step(), stimer.law(sd))
+                sctx.step_finish(y.duration_as_secs_f32(stimer.update_simulation_step(sd, v)))
         sctx.synchronize()
         sctx.close()
-        del sw, sctx, stimer
-    multi = None
-    k_steps = None  # the K timed steps in ONE library call (the caller's frame loop on the library's side), where the path has it
-    if world == 1 and not args.force_tiles:
-        n = n_global
+
+    def make_params():
+        params = y.default_params(device=dev_index, fixed_iterations=tuple(args.fixed_iterations))
+        if args.tolerance_scale != 1.0:
+            params.max_avg_density_error = float(np.float32(params.max_avg_density_error) * np.float32(args.tolerance_scale))
+            params.max_divergence_error = float(np.float32(params.max_divergence_error) * np.float32(args.tolerance_scale))
+        if args.lists_32bit:
+            params.list_span_limit = y.LISTS_32BIT
+        return params
+
+    fuse_div = os.environ.get("SPHX_FUSE_DIV", "1") != "0"
+
+    def traffic_of(name, n):
+        # HBM traffic of a kernel from the PMC counters: cannot be collected from inside the process; taken from the committed
+        # rocprofv3 passes of this same command (profiles/) when the workload matches, else null.
+        import glob
+
+        traffic, src = None, None
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_traffic_*.json"))):
+            try:
+                tj = json.load(open(tf))
+                if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
+                    traffic, src = tj["bytes_per_launch"][name]["total"], tj["source"] + f" [file {os.path.basename(tf)}" + (
+                        f", taken at git {tj['git_head']}]" if "git_head" in tj else "]")
+            except (OSError, KeyError, ValueError):
+                pass
+        return traffic, src
+
+    def measure(one_step, k_steps, ctx, barrier, steps, warmup, skip_steps, want_roofline, n, reduce_max=None):
+        """--skip-steps + --warmup untimed steps, then EXACTLY `steps` timed ones between two barriers.  Returns the timing, the step
+        statistics and the live roofline record of the dominant kernel."""
+        # Warm-up: every launch bracketed by hipEvents on the context's stream -> which kernel dominates a step.  (All ranks take the
+        # same decision: the kernel mix is the same on every tile.)
+        dominant, wprof = None, None
+        for _ in range(skip_steps):
+            one_step()
+        if want_roofline and warmup > 0:
+            ctx.profile_reset()
+            ctx.profile_filter(None)
+            ctx.profile_enable(True)
+        for _ in range(warmup):
+            one_step()
+        if want_roofline and warmup > 0:
+            ctx.profile_enable(False)
+            wprof = ctx.profile_get()
+            dominant = max(wprof.items(), key=lambda kv: kv[1]["total_ms"])[0] if wprof else None
+        if want_roofline and dominant is None:
+            dominant = "neighbor_build+density_alpha" if args.solver == "dfsph" else "neighbor_build"
+        # Timed region.  The dominant kernel alone keeps hipEvent records, around every 4th of its launches (sphx_profile_filter; all of
+        # them cost 2.6 % of the step rate, every 4th 0.7 %): its launch duration is measured live, over the steps `value` is computed
+        # from, on the stream it runs on.
+        if dominant is not None:
+            ctx.profile_reset()
+            ctx.profile_filter(dominant, 4)
+            ctx.profile_enable(True)
+        stats = []
+        barrier()
+        t0 = time.perf_counter()
+        if k_steps is not None and not args.per_step_calls:
+            stats = k_steps(steps)
+        else:
+            for _ in range(steps):
+                stats.append(one_step())
+        barrier()
+        elapsed = time.perf_counter() - t0
+        live, live_from = None, "timed region"
+        if dominant is not None:
+            ctx.profile_enable(False)
+            live = ctx.profile_get().get(dominant)
+            ctx.profile_filter(None)
+            if (live is None or not live["launches"]) and wprof and dominant in wprof:
+                # fewer than 4 timed launches of the dominant kernel (--steps < 4): the event-bracketed warm-up steps stand in
+                live, live_from = wprof[dominant], "warm-up steps (the timed region was too short to bracket a launch)"
+        if reduce_max is not None:
+            elapsed = reduce_max(elapsed)
+        roof = None
+        if live is not None and live["launches"]:
+            ev_ms = ctx.profile_event_overhead()  # what an EMPTY hipEvent bracket measures on this stream, same process
+            avg_raw = live["total_ms"] / live["launches"]
+            avg_ms = max(avg_raw - ev_ms, 1e-6)
+            ach = live["bytes"] / live["launches"] / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = traffic_of(dominant, n)
+            # per-kernel table (information only): a short extra pass with every launch timed, outside the timed region
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            extra = max(10, min(steps, 30))
+            for _ in range(extra):
+                one_step()
+            ctx.profile_enable(False)
+            prof = ctx.profile_get()
+            roof = {
+                "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "frac_of_achievable_6300": ach / HBM_ACHIEVABLE_GBS,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "avg_launch_ms_with_event_bracket": avg_raw,
+                "event_bracket_overhead_ms": ev_ms, "launches": live["launches"],
+                "algorithmic_bytes_per_launch": live["bytes"] / live["launches"],
+                "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream, minus the "
+                            "elapsed time of an empty event bracket measured in the same process" if live_from == "timed region" else
+                            "hipEvents around this kernel's launches, minus the elapsed time of an empty event bracket; taken from the " + live_from,
+                "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
+                "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (each adds the overhead above and keeps "
+                        "kernels from overlapping their neighbours' tails): its sum exceeds ms_per_step; information only",
+            }
+        return elapsed, stats, roof
+
+    def iteration_stats(stats):
+        return dict(Id=float(np.mean([s["density_iterations"] for s in stats])), Iv=float(np.mean([s["divergence_iterations"] for s in stats])),
+                    Wd=float(np.mean([s["warmstart_density"] for s in stats])), Wv=float(np.mean([s["warmstart_divergence"] for s in stats])),
+                    Id_max=int(max(s["density_iterations"] for s in stats)), Iv_max=int(max(s["divergence_iterations"] for s in stats)))
+
+    def step_model(kb, rb, it, n, steps, elapsed, measured_k):
+        # traversals the neighbour build does on the spot (SPHX_FUSE_DIV): one per step — the divergence loop's first
+        # compute_density_change, or that loop's warm start when it has one
+        folded = 1.0 if (fuse_div and args.solver == "dfsph") else 0.0
+        bstep_ref = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"])
+        bstep = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], compressed=not args.lists_32bit, rbar=rb, folded=folded)
+        return {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
+                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 16-bit slots (32-bit fallback per wavefront)",
+                "mean_neighbors": kb, "out_of_window_entries_per_particle": rb,
+                "k_and_r": "measured: list entries of the latest neighbour build / particles it ran over" if measured_k else "not measured",
+                "list_traversals_folded_into_the_neighbour_build_per_step": folded,
+                "achieved_GBs_whole_step_per_gpu": bstep * n * steps / elapsed / 1e9,
+                "frac_of_hbm_peak_whole_step": bstep * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                "frac_of_achievable_6300_whole_step": bstep * n * steps / elapsed / 1e9 / HBM_ACHIEVABLE_GBS,
+                "note": "at 1 M particles the working set (~170 MB) sits inside the 256 MB Infinity Cache: the HBM roofline is "
+                        "a soft bound there; 16 M (--particles 16000000) is the size where it binds"}
+
+    def single_window(particles, skip_steps, steps, warmup, want_roofline=True):
+        """One measurement on ONE context: the dam-break scaled to `particles`, `skip_steps` untimed steps, warm-up, timed steps."""
+        prewarm(particles)
+        scale, w = scene_of(particles)
+        pos, boundary = w.positions, w.boundary_particles
+        n = len(pos)
+        diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
+        timer = y.TimeManager(cfl_factor=0.2) if args.solver == "wcsph" else y.TimeManager()
+        params = make_params()
+        k_steps = None
         if args.no_device_dt or args.abi_calls:
             # the raw two-phase C ABI, one ctypes call per phase (A/B runs)
+            solver = None
             ctx = y.SphxContext(params)
             ctx.set_boundary(boundary)
             ctx.upload(pos)
@@ -288,54 +473,147 @@ def main():
             def k_steps(k):
                 return solver.simulation_steps(w, timer, k, sync_world=False)
 
+        def barrier():
+            torch.cuda.synchronize()
+            ctx.synchronize()
+
+        elapsed, stats, roof = measure(one_step, k_steps, ctx, barrier, steps, warmup, skip_steps, want_roofline, n)
+        it = iteration_stats(stats)
+        kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n
+        rbar = float(np.mean([s.get("remote_entries", 0) for s in stats])) / n
+        res = dict(scale=scale, n=n, n_boundary=len(boundary), elapsed=elapsed, steps=steps, warmup=warmup, skip_steps=skip_steps, it=it, kbar=kbar, rbar=rbar,
+                   roof=roof, value=n * steps / elapsed, ms_per_step=elapsed / steps * 1e3, model=step_model(kbar, rbar, it, n, steps, elapsed, True))
+        if solver is not None and hasattr(solver, "close"):
+            solver.close()
+        elif solver is None:
+            ctx.close()
+        return res
+
+    def window_summary(r, label):
+        """The compact form of a further window for the `also` list of the line."""
+        o = {"window": label, "value": r["value"], "unit": "particle-steps/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+             "skip_steps": r["skip_steps"], "particles": r["n"], "mean_density_iterations": r["it"]["Id"], "mean_divergence_iterations": r["it"]["Iv"],
+             "warmstart_rate": [r["it"]["Wd"], r["it"]["Wv"]], "mean_neighbors": r["kbar"],
+             "frac_of_hbm_peak_whole_step": r["model"]["frac_of_hbm_peak_whole_step"], "bytes_per_particle_step": r["model"]["bytes_per_particle_step"]}
+        if r["roof"]:
+            o["dominant_kernel"] = {k: r["roof"][k] for k in ("kernel", "avg_launch_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "traffic")}
+        return o
+
+    config_name = {1: "BASELINE configs[1]", 4: "BASELINE configs[3] (64 M, 2x2 tiles)", 8: "BASELINE configs[4] (128 M, 8 strips)"}
+    multi = None
+    if world == 1 and not args.force_tiles:
+        head = single_window(args.particles, args.skip_steps, args.steps, args.warmup, want_roofline=not args.no_roofline)
+        also = []
+        if args.also:
+            # the windows the headline does not show (VERDICT r02 item 2): configs[2] — 16 M particles, where the HBM roofline binds — and
+            # the iterating regime of the reference scene (after 3 750 steps the divergence loop needs two iterations and a warm start)
+            also.append(window_summary(single_window(16_000_000, 0, 20, 2), "DFSPH 16 M particles from t=0 (BASELINE configs[2])"))
+            also.append(window_summary(single_window(1_000_000, 3750, 100, 5), "DFSPH 1 M particles after 3750 steps (iterating regime: Iv = 2 with warm start)"))
+        n_global, n, scale = head["n"], head["n"], head["scale"]
+        out = {
+            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break" if args.solver == "dfsph" else "particle-steps/sec, 2D WCSPH dam-break",
+            "value": head["value"],
+            "unit": "particle-steps/s",
+            "n_gpus": 1,
+            "world_size_seen": 1,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {head['n_boundary']} boundary particles "
+                            f"on one GPU, adaptive CFL timer from t=0"
+                            + (f" = {config_name[1]}" if (args.solver == "dfsph" and abs(n_global - 1_000_000) < 20_000 and not args.skip_steps) else "")
+                            + (f", window after {args.skip_steps} steps" if args.skip_steps else "")
+                            + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
+                            + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
+                "particles_per_gpu": n,
+                "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
+                "particles_total": n_global,
+                "parallelism": "single GPU",
+                "mean_density_iterations": head["it"]["Id"], "mean_divergence_iterations": head["it"]["Iv"], "warmstart_rate": [head["it"]["Wd"], head["it"]["Wv"]],
+                "mean_neighbors": head["kbar"],
+                "max_density_iterations_seen": head["it"]["Id_max"], "max_divergence_iterations_seen": head["it"]["Iv_max"],
+                "host_calls": "one library call runs the K timed steps (sphx_*_simulation_steps: the caller's frame loop, main.rs:348-350, "
+                              "in C; every step is a full Solver::simulation_step)" if not (args.per_step_calls or args.no_device_dt or args.abi_calls)
+                else "one library call per step from Python",
+                "solver_loop": "host-run (SPHX_HOST_LOOP=1)" if os.environ.get("SPHX_HOST_LOOP") == "1" else
+                "device-run (residual test on the device, iterations queued ahead)",
+            },
+            "step_model": head["model"],
+        }
+        if head["roof"]:
+            out["roofline"] = head["roof"]
+        if also:
+            out["also"] = also
+        if not args.no_cpu_baseline and args.solver == "dfsph":
+            out["cpu_baseline"] = cpu_baseline(scale)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return
+
+    # ---- tiles: N > 1 ranks (one per GPU), or --force-tiles on one ----------------------------------------------------------------
+    if args.solver == "wcsph":
+        raise SystemExit("--solver wcsph runs on one GPU")
+    # weak scaling: the global scene holds `particles` per GPU
+    prewarm(args.particles)
+    scale, w = scene_of(args.particles * world)
+    pos, boundary = w.positions, w.boundary_particles
+    n_global = len(pos)
+    diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
+    timer = y.TimeManager()
+    params = make_params()
+    # The tile step loop runs INSIDE libsphx (sphx_multi, csrc/sphx_tiles.cpp): this process holds one tile.  Transport of the halo
+    # records: the library's own grouped ncclSend/ncclRecv (RCCL over xGMI) with shared-memory scalars, or — --comm torch, and
+    # always over gloo — torch.distributed through the sphx_comm_ops function table.
+    from yasph2d_amd import _lib as ylib
+    from yasph2d_amd.multi import MultiSolver, TorchCommOps
+
+    lay = {"auto": ylib.LAYOUT_AUTO, "strips": ylib.LAYOUT_STRIPS, "grid": ylib.LAYOUT_GRID}[args.tiles]
+    kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay, overlap_exchange=args.overlap_exchange)
+    job = "bench" + os.environ.get("MASTER_PORT", "0")
+    if dist is not None:
+        # a per-run token in the segment's name on top of the library's own stale-segment handshake
+        tok = [os.urandom(4).hex() if rank == 0 else None]
+        dist.broadcast_object_list(tok, src=0)
+        job += "_" + tok[0]
+    if dist is None:
+        multi = MultiSolver(params, devices=[dev_index], **kw)  # --force-tiles: one tile, the tile code path
     else:
-        # The tile step loop runs INSIDE libsphx (sphx_multi, csrc/sphx_tiles.cpp): this process holds one tile.  Transport of the halo
-        # records: the library's own grouped ncclSend/ncclRecv (RCCL over xGMI) with shared-memory scalars, or — --comm torch, and
-        # always over gloo — torch.distributed through the sphx_comm_ops function table.
-        from yasph2d_amd import _lib as ylib
-        from yasph2d_amd.multi import MultiSolver, TorchCommOps
+        use_builtin = args.comm == "rccl" or (args.comm == "auto" and args.backend == "nccl")
+        if use_builtin:
+            try:
+                multi = MultiSolver.rank(params, dev_index, rank, world, comm=None, job=job, **kw)
+                ok = 1.0
+            except y.SphxError as e:
+                # (the library's bring-up fails on EVERY rank together — status rounds over the shared segment — so nobody hangs here)
+                sys.stderr.write(f"bench.py: rank {rank}: built-in RCCL transport failed ({e}); falling back to torch.distributed\n")
+                ok = 0.0
+            t = torch.tensor([ok], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)  # all ranks take the same decision
+            if float(t.item()) < 1.0:
+                if multi is not None:
+                    multi.close()
+                multi, use_builtin = None, False
+        if not use_builtin:
+            comm = TorchCommOps(dist, torch.device("cuda", dev_index), shm_name=job + "t" if args.scalar_comm == "shm" else None)
+            multi = MultiSolver.rank(params, dev_index, rank, world, comm=comm, **kw)
+    multi.set_boundary(boundary)
+    multi.upload(pos)
+    ctx = multi.tile_context(0)
+    n = n_global // world
 
-        lay = {"auto": ylib.LAYOUT_AUTO, "strips": ylib.LAYOUT_STRIPS, "grid": ylib.LAYOUT_GRID}[args.tiles]
-        kw = dict(halo=args.halo, fixed_halo=args.fixed_halo, rebalance_every=args.rebalance_every, layout=lay, overlap_exchange=args.overlap_exchange)
-        job = "bench" + os.environ.get("MASTER_PORT", "0")
-        if dist is not None:
-            # the shared-memory segment of the scalar all-reduce is found by name: a token chosen by rank 0 keeps a segment a crashed
-            # earlier run with the same port may have left behind from being opened by a rank that gets there before rank 0
-            tok = [os.urandom(4).hex() if rank == 0 else None]
-            dist.broadcast_object_list(tok, src=0)
-            job += "_" + tok[0]
-        if dist is None:
-            multi = MultiSolver(params, devices=[dev_index], **kw)  # --force-tiles: one tile, the tile code path
-        else:
-            use_builtin = args.comm == "rccl" or (args.comm == "auto" and args.backend == "nccl")
-            if use_builtin:
-                try:
-                    multi = MultiSolver.rank(params, dev_index, rank, world, comm=None, job=job, **kw)
-                    ok = 1.0
-                except y.SphxError as e:
-                    sys.stderr.write(f"bench.py: rank {rank}: built-in RCCL transport failed ({e}); falling back to torch.distributed\n")
-                    ok = 0.0
-                t = torch.tensor([ok], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)  # all ranks take the same decision
-                if float(t.item()) < 1.0:
-                    if multi is not None:
-                        multi.close()
-                    multi, use_builtin = None, False
-            if not use_builtin:
-                comm = TorchCommOps(dist, torch.device("cuda", dev_index), shm_name=job + "t" if args.scalar_comm == "shm" else None)
-                multi = MultiSolver.rank(params, dev_index, rank, world, comm=comm, **kw)
-        multi.set_boundary(boundary)
-        multi.upload(pos)
-        ctx = multi.tile_context(0)
-        n = n_global // world
+    def one_step():
+        st = multi.step(timer, diam)
+        st["neighbor_entries"] = 0
+        return st
 
-        def one_step():
-            st = multi.step(timer, diam)
-            st["neighbor_entries"] = 0
-            return st
-
-        def k_steps(k):
-            return multi.steps(timer, k, diam)
+    def k_steps(k):
+        return multi.steps(timer, k, diam)
 
     def barrier():
         if dist is not None:
@@ -343,110 +621,32 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    # Warm-up: every launch bracketed by hipEvents on the context's stream -> which kernel dominates a step.  (All ranks take the
-    # same decision: the kernel mix is the same on every tile.)
-    dominant = None
-    wprof = None
-    if not args.no_roofline and args.warmup > 0:
-        ctx.profile_reset()
-        ctx.profile_filter(None)
-        ctx.profile_enable(True)
-    for _ in range(args.skip_steps + args.warmup):
-        one_step()
-    if not args.no_roofline and args.warmup > 0:
-        ctx.profile_enable(False)
-        wprof = ctx.profile_get()
-        dominant = max(wprof.items(), key=lambda kv: kv[1]["total_ms"])[0] if wprof else None
-    if not args.no_roofline and dominant is None:
-        dominant = "neighbor_build+density_alpha" if args.solver == "dfsph" else "neighbor_build"
-
-    # Timed region.  The dominant kernel alone keeps hipEvent records, around every 4th of its launches (sphx_profile_filter; all of
-    # them cost 2.6 % of the step rate, every 4th 0.7 %): its launch duration is measured live, over the steps `value` is computed
-    # from, on the stream it runs on.
-    if dominant is not None:
-        ctx.profile_reset()
-        ctx.profile_filter(dominant, 4)
-        ctx.profile_enable(True)
-    stats = []
-    barrier()
-    t0 = time.perf_counter()
-    if k_steps is not None and not args.per_step_calls:
-        stats = k_steps(args.steps)
-    else:
-        for _ in range(args.steps):
-            stats.append(one_step())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    live = None
-    if dominant is not None:
-        ctx.profile_enable(False)
-        live = ctx.profile_get().get(dominant)
-        ctx.profile_filter(None)
-        live_from = "timed region"
-        if (live is None or not live["launches"]) and wprof and dominant in wprof:
-            # fewer than 4 timed launches of the dominant kernel (--steps < 4): the event-bracketed warm-up steps stand in
-            live, live_from = wprof[dominant], "warm-up steps (the timed region was too short to bracket a launch)"
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    Id = float(np.mean([s["density_iterations"] for s in stats]))
-    Iv = float(np.mean([s["divergence_iterations"] for s in stats]))
-    Wd = float(np.mean([s["warmstart_density"] for s in stats]))
-    Wv = float(np.mean([s["warmstart_divergence"] for s in stats]))
-    kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n if multi is None else None
-    minfo = multi.info() if multi is not None else None
-
-    roof = None
-    if live is not None and live["launches"]:
-        name, rec = dominant, live
-        ev_ms = ctx.profile_event_overhead()  # what an EMPTY hipEvent bracket measures on this stream, same process
-        avg_raw = rec["total_ms"] / rec["launches"]
-        avg_ms = max(avg_raw - ev_ms, 1e-6)
-        ach = rec["bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
-        # HBM traffic of that kernel from the PMC counters: cannot be collected from inside the process; taken from the committed
-        # rocprofv3 passes of this same command (profiles/) when the workload matches, else null.
-        traffic, traffic_src = None, None
-        import glob
-
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_traffic_*.json"))):
-            try:
-                tj = json.load(open(tf))
-                if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
-                    traffic, traffic_src = tj["bytes_per_launch"][name]["total"], tj["source"]
-            except (OSError, KeyError, ValueError):
-                pass
-        # per-kernel table (information only): a short extra pass with every launch timed, outside the timed region
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        extra = max(10, min(args.steps, 30))
-        for _ in range(extra):
-            one_step()
-        ctx.profile_enable(False)
-        prof = ctx.profile_get()
-        roof = {
-            "bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "frac_of_achievable_6300": ach / HBM_ACHIEVABLE_GBS,
-            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "avg_launch_ms_with_event_bracket": avg_raw,
-            "event_bracket_overhead_ms": ev_ms, "launches": rec["launches"],
-            "algorithmic_bytes_per_launch": rec["bytes"] / rec["launches"],
-            "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream, minus the "
-                        "elapsed time of an empty event bracket measured in the same process" if live_from == "timed region" else
-                        "hipEvents around this kernel's launches, minus the elapsed time of an empty event bracket; taken from the " + live_from,
-            "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
-            "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (each adds the overhead above and keeps "
-                    "kernels from overlapping their neighbours' tails): its sum exceeds ms_per_step; information only",
-        }
-
+    elapsed, stats, roof = measure(one_step, k_steps, ctx, barrier, args.steps, args.warmup, args.skip_steps, not args.no_roofline, n, reduce_max)
+    it = iteration_stats(stats)
+    minfo = multi.info()
+    # measured list statistics of the tiles' latest neighbour build, summed over the ranks; per-rank owned counts
+    tot = [float(minfo["neighbor_entries"]), float(minfo["remote_entries"]), float(minfo["build_particles"])]
+    owned = [int(minfo["owned_local"])]
+    if dist is not None:
+        t = torch.tensor(tot, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        tot = t.tolist()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, owned[0])
+        owned = [int(v) for v in gathered]
+    kbar = tot[0] / tot[2] if tot[2] else None
+    rbar = tot[1] / tot[2] if tot[2] else None
     if rank == 0:
         value = n_global * args.steps / elapsed
-        kb = kbar if kbar is not None else 8.0  # tiles do not report k; 8.0 = lattice value
-        rb = float(np.mean([s.get("remote_entries", 0) for s in stats])) / n if multi is None else 0.5
-        bstep_ref = bytes_per_particle_step(kb, Id, Iv, Wd, Wv)
-        bstep = bytes_per_particle_step(kb, Id, Iv, Wd, Wv, compressed=not args.lists_32bit, rbar=rb)
         out = {
-            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break" if args.solver == "dfsph" else "particle-steps/sec, 2D WCSPH dam-break",
+            "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break",
             "value": value,
             "unit": "particle-steps/s",
             "n_gpus": world,
@@ -460,50 +660,41 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
+                "workload": f"DFSPH 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {len(boundary)} boundary particles "
                             f"in total ({n} fluid per GPU), adaptive CFL timer from t=0"
+                            + (f" = {config_name[world]}" if (world in (4, 8) and abs(n - 16_000_000) < 300_000 and not args.skip_steps) else "")
                             + (f", window after {args.skip_steps} steps" if args.skip_steps else "")
                             + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
+                "owned_particles_per_rank": owned,
                 "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
                 "particles_total": n_global,
-                "parallelism": "single GPU" if multi is None else
+                "transport": minfo["transport"],
+                "parallelism":
                 f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
                 f"particle-count quantiles), step loop inside libsphx (sphx_multi), ghost halo {minfo['halo_now']} of <= {args.halo} cells (follows "
                 f"the ring budget), per step: 1 halo exchange with {minfo['peers']} neighbours + 3 scalar all-reduces; transport: "
                 f"{minfo['transport']}; {minfo['exchanges']} exchanges and {minfo['rebalances']} re-partitions in total",
-                "mean_density_iterations": Id, "mean_divergence_iterations": Iv, "warmstart_rate": [Wd, Wv], "mean_neighbors": kbar,
-                "max_density_iterations_seen": int(max(s["density_iterations"] for s in stats)),
-                "max_divergence_iterations_seen": int(max(s["divergence_iterations"] for s in stats)),
+                "mean_density_iterations": it["Id"], "mean_divergence_iterations": it["Iv"], "warmstart_rate": [it["Wd"], it["Wv"]], "mean_neighbors": kbar,
+                "max_density_iterations_seen": it["Id_max"], "max_divergence_iterations_seen": it["Iv_max"],
                 "host_calls": "one library call runs the K timed steps (sphx_*_simulation_steps: the caller's frame loop, main.rs:348-350, "
-                              "in C; every step is a full Solver::simulation_step)" if (k_steps is not None and not args.per_step_calls)
-                else "one library call per step from Python",
-                "solver_loop": "host-run (SPHX_HOST_LOOP=1)" if os.environ.get("SPHX_HOST_LOOP") == "1" else
-                "device-run (residual test on the device, iterations queued ahead)" if multi is None else "host-run with an all-reduce per iteration",
+                              "in C; every step is a full Solver::simulation_step)" if not args.per_step_calls else "one library call per step from Python",
+                "solver_loop": "tile loop: the verdict of every solver iteration needs the all-reduce over the tiles",
             },
-            "step_model": {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
-                           "list_format": "32-bit" if args.lists_32bit else "workgroup-local 16-bit slots (32-bit fallback per wavefront)",
-                           "out_of_window_entries_per_particle": rb,
-                           "achieved_GBs_whole_step_per_gpu": bstep * n * args.steps / elapsed / 1e9,
-                           "frac_of_hbm_peak_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                           "frac_of_achievable_6300_whole_step": bstep * n * args.steps / elapsed / 1e9 / HBM_ACHIEVABLE_GBS,
-                           "note": "at 1 M particles the working set (~170 MB) sits inside the 256 MB Infinity Cache: the HBM roofline is "
-                                   "a soft bound there; 16 M (--particles 16000000) is the size where it binds"},
+            "step_model": step_model(kbar if kbar is not None else 8.0, rbar if rbar is not None else 0.5, it, n, args.steps, elapsed, kbar is not None),
         }
         if roof:
             out["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1 and args.solver == "dfsph":
-            out["cpu_baseline"] = cpu_baseline(pos, boundary)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if multi is not None:  # tiles, their communicator and the shared-memory segment of the scalar all-reduce (rank 0 unlinks it)
-        comm_obj = getattr(multi, "_comm", None)
-        if dist is not None:
-            dist.barrier()
-        multi.close()
-        if comm_obj is not None and hasattr(comm_obj, "close"):
-            comm_obj.close()
+    # tiles, their communicator and the shared-memory segment of the scalar all-reduce (rank 0 unlinks it)
+    comm_obj = getattr(multi, "_comm", None)
+    if dist is not None:
+        dist.barrier()
+    multi.close()
+    if comm_obj is not None and hasattr(comm_obj, "close"):
+        comm_obj.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

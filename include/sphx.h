@@ -265,12 +265,18 @@ typedef struct sphx_comm_ops {
     int rank, world;
     int (*exchange)(void* user, const int* peers, int n_peers, void* const* d_send, void* const* d_recv, size_t bytes, void* hip_stream);
     int (*allreduce)(void* user, const double* in, int n, int op, double* out);
+    /* optional (may be NULL): this rank has failed and will not take part in further calls — release the ranks waiting for it */
+    void (*abort)(void* user);
 } sphx_comm_ops;
 typedef struct sphx_multi_info_t {
     uint32_t world, local_tiles, halo_now, halo_max, peers, n_local, cap_records, grid_layout;
     int32_t axis;
     uint32_t reserved;
     uint64_t exchanges, rebalances;
+    /* the local tiles' latest neighbour build (measured, not assumed): particles it ran over (owned + ghosts), list entries, and
+     * entries outside the workgroup windows — mean list length = neighbor_entries / build_particles */
+    uint64_t build_particles, neighbor_entries, remote_entries;
+    uint64_t owned_local; /* particles the local tiles own */
     char transport[96];
 } sphx_multi_info_t;
 int sphx_multi_default_options(sphx_multi_options* out);
@@ -314,13 +320,21 @@ int sphx_multi_simulation_steps(sphx_multi* m, struct sphx_timer* timer, float p
  * rank; for one process per GPU on ONE node a shared-memory all-reduce costs ~1 us instead of a device round trip through
  * RCCL.  RCCL is used where the path really exchanges data (the halo records).  name: unique per job (e.g. MASTER_PORT). */
 typedef struct sphx_shm sphx_shm;
+/* Collective: every rank of the run calls it (in any order); it returns once all `world` ranks have joined the SAME segment — rank 0
+ * replaces whatever an earlier run left under the name, a rank that attached to such a leftover notices (nobody answers its join
+ * token) and attaches again.  NULL on failure or when a rank does not show up within min(SPHX_SHM_TIMEOUT_S, 120) seconds. */
 sphx_shm* sphx_shm_open(const char* name, int rank, int world);
-/* op: 0 = sum, 1 = max; n <= 8 doubles; every rank gets the same bits (ranks are combined in rank order) */
+/* op: 0 = sum, 1 = max; n <= 8 doubles; every rank gets the same bits (ranks are combined in rank order).  Returns
+ * SPHX_ERR_NOT_READY — on every waiting rank, at once — when a rank has called sphx_shm_abort / sphx_shm_close instead of arriving, or
+ * after SPHX_SHM_TIMEOUT_S seconds (default 300) without it. */
 int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out);
+void sphx_shm_abort(sphx_shm* h); /* this rank has failed: release the ranks that wait for it */
 void sphx_shm_close(sphx_shm* h);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 int sphx_synchronize(sphx_ctx* ctx);
+/* the latest neighbour build of this context: particles it ran over, list entries in total, entries outside the workgroup windows */
+int sphx_build_stats(const sphx_ctx* ctx, uint32_t* out_particles, uint64_t* out_entries, uint64_t* out_remote);
 /* Run this context on a HIP stream owned by the caller (hipStream_t; NULL = back to a private stream).  The tile driver passes
  * the stream RCCL orders its sends/receives against, so packing, exchange and unpacking need no host synchronisation. */
 int sphx_set_stream(sphx_ctx* ctx, void* hip_stream);

@@ -80,6 +80,9 @@ def lib(omp=False):
         "orc_kernel_constants": (None, [i32, f32, vp]),
         "orc_set_threads": (None, [i32]),
         "orc_get_max_threads": (i32, []),
+        "orc_set_all_parallel": (None, [i32]),
+        "orc_get_proc_bind": (i32, []),
+        "orc_get_num_places": (i32, []),
         "orc_create": (vp, [C.POINTER(OrcParams)]),
         "orc_destroy": (None, [vp]),
         "orc_get_properties": (None, [vp, vp]),

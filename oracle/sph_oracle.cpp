@@ -37,6 +37,11 @@
 // liboracle_omp.so (-fopenmp -DORC_OMP) puts `#pragma omp parallel for` exactly on the loops
 // the reference runs through rayon (par_iter / par_windows / par_sort) and leaves the
 // reference's serial loops serial — it is the "port" CPU baseline timed by bench.py.
+// orc_set_all_parallel(1) (OpenMP build only) additionally runs the loops the reference leaves serial — cell indices,
+// apply_sorting, the max-velocity scan, the velocity prediction, the warm-start clamps — in parallel: the "all_parallel"
+// variant SURVEY.md 8(d) allows beside the faithful one (same results: none of those loops carries an order).
+// Per-step vectors (predicted_velocities, accellerations, density_error, the sort scratch) are pooled across steps like the
+// reference's ScratchBufferStore does (scratch_buffer.rs:64-90) instead of being allocated every step.
 // =====================================================================================
 #include <algorithm>
 #include <atomic>
@@ -48,6 +53,14 @@
 #ifdef ORC_OMP
 #include <omp.h>
 #include <parallel/algorithm>
+#endif
+
+static int g_all_parallel = 0;  // orc_set_all_parallel
+#ifdef ORC_OMP
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PAR_IF_ALL ORC_PRAGMA(omp parallel for schedule(static) if (g_all_parallel))
+#else
+#define ORC_PAR_IF_ALL
 #endif
 
 typedef float Real;
@@ -353,10 +366,20 @@ struct CompactMortonCellGrid {  // :66-260
     std::vector<uint32_t> last_sorting;  // kept so callers can permute their own attributes (ids)
     CompactMortonCellGrid() { cells.push_back(MortonCell{0, 0xFFFFFFFFu}); }  // :80-87
 
+    // pooled scratch (scratch_buffer.rs:64-90): one buffer per element size, swapped with the sorted array
+    std::vector<V2> scratch_v2;
+    std::vector<Real> scratch_real;
+    std::vector<uint32_t> scratch_uint, cell_indices_pool;
+    std::vector<V2>& scratch_of(const std::vector<V2>&) { return scratch_v2; }
+    std::vector<Real>& scratch_of(const std::vector<Real>&) { return scratch_real; }
+    std::vector<uint32_t>& scratch_of(const std::vector<uint32_t>&) { return scratch_uint; }
     template <class T>
-    static void apply_sorting(const std::vector<uint32_t>& sorting, std::vector<T>& buf) {  // :71-78 (serial)
-        std::vector<T> scratch(buf.size());
-        for (size_t k = 0; k < buf.size(); ++k) scratch[k] = buf[sorting[k]];
+    void apply_sorting(const std::vector<uint32_t>& sorting, std::vector<T>& buf) {  // :71-78 (serial)
+        std::vector<T>& scratch = scratch_of(buf);
+        scratch.resize(buf.size());
+        const long nn = (long)buf.size();
+        ORC_PAR_IF_ALL
+        for (long k = 0; k < nn; ++k) scratch[k] = buf[sorting[k]];
         buf.swap(scratch);
     }
 
@@ -366,8 +389,10 @@ struct CompactMortonCellGrid {  // :66-260
         const size_t n = positions.size();
         std::vector<uint32_t>& particle_indices = last_sorting;
         particle_indices.resize(n);
-        std::vector<uint32_t> cell_indices(n);
-        for (size_t i = 0; i < n; ++i) {  // :111-114 (serial)
+        std::vector<uint32_t>& cell_indices = cell_indices_pool;
+        cell_indices.resize(n);
+        ORC_PAR_IF_ALL
+        for (long i = 0; i < (long)n; ++i) {  // :111-114 (serial)
             particle_indices[i] = (uint32_t)i;
             cell_indices[i] = grid.position_to_cidx(positions[i]);
         }
@@ -706,6 +731,9 @@ struct DFSPHSolver {  // dfsph.rs:16-41
     Real max_divergence_error;
     uint32_t max_num_divergence_correction_iterations, num_divergence_correction_iterations;
     std::vector<Real> alpha_values, warmstart_stiffness, warmstart_kappa;
+    // per-step scratch, pooled across steps (scratch_buffer.rs:64-90)
+    std::vector<V2> pool_predicted, pool_accel;
+    std::vector<Real> pool_error;
     uint32_t fixed_density_iterations = 0, fixed_divergence_iterations = 0;  // oracle extra: parity mode
 
     void init(Real h) {  // :43-61
@@ -855,12 +883,19 @@ struct DFSPHSolver {  // dfsph.rs:16-41
         st.warmstart_density = 0;
         if (num_density_correction_iterations > 1) {  // :199
             const Real lim = -0.5f * w.fluid_density * w.fluid_density;
-            for (auto& k : warmstart_kappa) k = 0.5f * rs_max(k, lim);  // :201-203 (serial)
+            const long nk = (long)warmstart_kappa.size();
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < nk; ++i) warmstart_kappa[i] = 0.5f * rs_max(warmstart_kappa[i], lim);  // :201-203 (serial)
             correct_warmstart(true, dt, w, velocities, warmstart_kappa);
             st.warmstart_density = 1;
         }
-        for (auto& k : warmstart_kappa) k = 0.0f;  // :206-208 (serial)
-        std::vector<Real> density_error(w.positions.size());
+        {
+            const long nk = (long)warmstart_kappa.size();
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < nk; ++i) warmstart_kappa[i] = 0.0f;  // :206-208 (serial)
+        }
+        std::vector<Real>& density_error = pool_error;  // (pooled: scratch_buffer.rs)
+        density_error.resize(w.positions.size());
         num_density_correction_iterations = 0;
         for (;;) {
             compute_density_error(dt, w, velocities, density_error);
@@ -915,12 +950,19 @@ struct DFSPHSolver {  // dfsph.rs:16-41
         st.warmstart_divergence = 0;
         if (num_divergence_correction_iterations > 1) {  // :354
             const Real lim = -0.5f * w.fluid_density * w.fluid_density;
-            for (auto& s : warmstart_stiffness) s = 0.5f * rs_max(s, lim);  // :356-358
+            const long nk = (long)warmstart_stiffness.size();
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < nk; ++i) warmstart_stiffness[i] = 0.5f * rs_max(warmstart_stiffness[i], lim);  // :356-358
             correct_warmstart(false, dt, w, velocities, warmstart_stiffness);
             st.warmstart_divergence = 1;
         }
-        for (auto& s : warmstart_stiffness) s = 0.0f;  // :361-363
-        std::vector<Real> density_change(w.positions.size());
+        {
+            const long nk = (long)warmstart_stiffness.size();
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < nk; ++i) warmstart_stiffness[i] = 0.0f;  // :361-363
+        }
+        std::vector<Real>& density_change = pool_error;
+        density_change.resize(w.positions.size());
         num_divergence_correction_iterations = 0;
         for (;;) {
             compute_density_change(w, velocities, density_change);
@@ -949,11 +991,13 @@ struct DFSPHSolver {  // dfsph.rs:16-41
             w.update_densities(kernel);
             compute_alpha_factors(w);
         }
-        std::vector<V2> predicted_velocities(n);
+        std::vector<V2>& predicted_velocities = pool_predicted;  // (pooled: scratch_buffer.rs:64-90; swapped with velocities at :524)
+        predicted_velocities.resize(n);
         Real dt = duration_as_secs_f32(tm.simulation_step());  // :433
         st.dt_prev = dt;
         {
-            std::vector<V2> accellerations(n);
+            std::vector<V2>& accellerations = pool_accel;
+            accellerations.resize(n);
             {  // :436-469 non-pressure forces
                 const Real particle_mass = w.particle_mass();
                 const V2 non_pressure_forces = w.gravity * particle_mass;
@@ -979,12 +1023,21 @@ struct DFSPHSolver {  // dfsph.rs:16-41
             }
             {  // :472-481 update timestep (serial)
                 Real max_velocity_sq = 0.0f;
+                if (g_all_parallel) {
+#ifdef ORC_OMP
+                    // (max over finite non-negative values: the same value in any order; a NaN — which rs_max would drop unless it came
+                    // first — makes the step fail in either form)
+#pragma omp parallel for schedule(static) reduction(max : max_velocity_sq)
+#endif
+                    for (long i = 0; i < (long)n; ++i) max_velocity_sq = rs_max(max_velocity_sq, magnitude2(w.velocities[i] + accellerations[i] * dt));
+                } else
                 for (size_t i = 0; i < n; ++i) max_velocity_sq = rs_max(max_velocity_sq, magnitude2(w.velocities[i] + accellerations[i] * dt));
                 st.vmax = std::sqrt(max_velocity_sq);
                 dt = duration_as_secs_f32(tm.update_simulation_step(w.particle_radius() * 2.0f, st.vmax));
                 st.dt = dt;
             }
-            for (size_t i = 0; i < n; ++i) predicted_velocities[i] = w.velocities[i] + accellerations[i] * dt;  // :484-492 (serial)
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < (long)n; ++i) predicted_velocities[i] = w.velocities[i] + accellerations[i] * dt;  // :484-492 (serial)
         }
         correct_density_error(dt, w, predicted_velocities, st);  // :496
         {                                                          // :499-510 advect (parallel)
@@ -1173,6 +1226,22 @@ void orc_set_threads(int n) {
     omp_set_num_threads(n);
 #else
     (void)n;
+#endif
+}
+void orc_set_all_parallel(int on) { g_all_parallel = on ? 1 : 0; }
+// what the OpenMP runtime this library is bound to really does with the threads (bench.py reports these, not environment strings)
+int orc_get_proc_bind() {
+#ifdef ORC_OMP
+    return (int)omp_get_proc_bind();
+#else
+    return 0;
+#endif
+}
+int orc_get_num_places() {
+#ifdef ORC_OMP
+    return omp_get_num_places();
+#else
+    return 0;
 #endif
 }
 int orc_get_max_threads() {

@@ -30,6 +30,20 @@ def test_gpus_flag_starts_that_many_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] is None
 
 
+@pytest.mark.parametrize("gpus,total,name", [(4, 64, "configs[3]"), (8, 128, "configs[4]")])
+def test_default_multi_gpu_workload_is_the_baseline_config(gpus, total, name):
+    """`bench.py --gpus N` without --particles: 16 M particles per GPU, i.e. BASELINE configs[3] on 4 GPUs (64 M, 2x2) and configs[4]
+    on 8 (128 M, strips) — what a driver run with only --steps/--warmup times."""
+    rc, out, err = run(["--gpus", str(gpus), "--dry-run"])
+    assert rc == 0, err
+    d = json.loads([ln for ln in out.splitlines() if ln.strip()][-1])
+    wl = d["config"]["workload"]
+    assert d["n_gpus"] == gpus and d["config"]["particles_per_gpu"] == 16_000_000
+    assert name in wl and f"{total} M" in wl, wl
+    n_total = int(wl.split("~")[1].split(" ")[0])
+    assert abs(n_total - total * 1_000_000) < 0.01 * total * 1_000_000, wl
+
+
 def test_world_size_must_match_gpus():
     rc, out, err = run(["--gpus", "2", "--dry-run"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert rc != 0 and out.strip() == ""
@@ -55,3 +69,7 @@ def test_two_ranks_share_the_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["value"] > 0
     assert d["config"]["particles_total"] > 30000
+    # measured, not assumed: list statistics and ownership come from the tiles
+    assert 6.0 < d["config"]["mean_neighbors"] < 14.0 and d["step_model"]["k_and_r"].startswith("measured")
+    assert len(d["config"]["owned_particles_per_rank"]) == 2 and sum(d["config"]["owned_particles_per_rank"]) == d["config"]["particles_total"]
+    assert "transport" in d["config"]

@@ -242,3 +242,92 @@ def test_regrid_with_a_folded_divergence_pass_keeps_its_contract():
     assert L.sphx_sub_regrid_warm(ctx, C.byref(n)) == 0
     assert L.sphx_sub_warmstart(ctx, 1, dt) == 0                            # accepted, nothing launched
     assert L.sphx_sub_iteration(ctx, 1, dt, 1, C.byref(s), C.byref(owned)) == 0
+
+
+def test_multi_solver_keeps_particles_appended_behind_a_headless_world():
+    """Round-2 advisor finding: HipDfsphMultiSolver::simulation_step fetched the stale prefix with sync_world(), which shrank the host
+    arrays to the owned particles — the particles the caller had appended since (add_fluid_rect after headless steps) were dropped
+    and the upload read past the vectors.  Headless and synced stepping must see the same scene: same particle count, same
+    iteration counts and time steps, same state particle for particle (the two runs cut the same tiles from the same arrays)."""
+
+    def run(sync):
+        w = y.FluidParticleWorld()
+        w.reset_fluid(1.0)
+        t = y.TimeManager()
+        s = y.DFSPHMultiSolver(w, devices=[0, 0])
+        st = [s.simulation_step(w, t, sync_world=sync) for _ in range(25)]
+        w.add_fluid_rect(1.2, 1.0, 0.2, 0.2, 0.05)  # appended behind the particles the tiles are working on
+        n_after_edit = w.num_dynamic_particles
+        st += [s.simulation_step(w, t, sync_world=sync) for _ in range(10)]
+        s.sync_world(w)
+        return n_after_edit, w.num_dynamic_particles, np.array(w.positions), np.array(w.velocities), t.total_simulated_ns, [x["divergence_iterations"] for x in st]
+
+    ea, na, pa, va, ta, ia = run(True)
+    eb, nb, pb, vb, tb, ib = run(False)
+    assert na == nb == ea > 4050, (ea, eb, na, nb)
+    assert ta == tb and ia == ib
+    # the host order after a sync is tile after tile; compare as sets of (position, velocity) records
+    ra = np.sort(np.ascontiguousarray(np.concatenate([pa, va], axis=1)).view([("", np.float32)] * 4).ravel())
+    rb = np.sort(np.ascontiguousarray(np.concatenate([pb, vb], axis=1)).view([("", np.float32)] * 4).ravel())
+    assert np.array_equal(ra, rb)
+
+
+def test_sphx_multi_four_tiles_at_4M_against_the_single_context():
+    """The C++ tile loop itself (sphx_multi, not its Python reference) at a size where things happen: 4 M particles on 2 x 2 tiles
+    of ONE device, started from a deliberately skewed cut (30 % / 70 % columns) so that the re-partitioning has work to do, with the
+    adaptive ghost band.  Against the single context on the same scene, by particle id: bit-equal after the first step (no
+    migration yet), summation-order accuracy after 24 steps; every particle owned exactly once; cuts moved, band narrowed; the
+    measured list statistics of the tiles (sphx_multi_info) agree with the single context's."""
+    pos, boundary = dam_break(float(np.sqrt(4.0e6 / 4050.0)))
+    n = len(pos)
+    assert n > 3_900_000
+    steps = 24
+    # single context
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    single = {}
+    for k in range(1, steps + 1):
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
+        st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(np.float32(0.01), vmax)))
+        if k in (1, steps):
+            single[k] = (by_id({kk: vv for kk, vv in ctx.download(density=False).items() if kk in ("ids", "pos", "vel")}), st, timer.simulation_step_ns())
+    kbar_single = st["neighbor_entries"] / n
+    ctx.close()
+    # four tiles, skewed start
+    cx, cy = cell_coord(pos, 0), cell_coord(pos, 1)
+    xs = np.sort(cx)
+    xcuts = [0, int(xs[int(0.3 * n)]), 65536]
+    ycuts = []
+    for ix in range(2):
+        col = cy[(cx >= xcuts[ix]) & (cx < xcuts[ix + 1])]
+        ycuts.append([0, int(np.sort(col)[len(col) // 2]), 65536])
+    m = MultiSolver(y.default_params(), devices=[0, 0, 0, 0], rebalance_every=4)
+    m.set_grid(xcuts, np.array(ycuts, np.uint32))
+    m.set_boundary(boundary)
+    m.upload(pos)
+    t2 = y.TimeManager()
+    st1 = m.step(t2)
+    a1 = by_id({k: v for k, v in m.download().items() if k in ("ids", "pos", "vel")})
+    ref1, rst1, rdt1 = single[1]
+    np.testing.assert_array_equal(a1["ids"], np.arange(n, dtype=np.uint32))  # every particle owned exactly once
+    assert_bits_equal(a1["pos"], ref1["pos"], "pos after one step")
+    assert_bits_equal(a1["vel"], ref1["vel"], "vel after one step")
+    assert (st1["density_iterations"], st1["divergence_iterations"], st1["dt_ns"]) == (rst1["density_iterations"], rst1["divergence_iterations"], rdt1)
+    stats = m.steps(t2, steps - 1)
+    ak = by_id({k: v for k, v in m.download().items() if k in ("ids", "pos", "vel")})
+    refk, rstk, rdtk = single[steps]
+    np.testing.assert_array_equal(ak["ids"], np.arange(n, dtype=np.uint32))
+    np.testing.assert_allclose(ak["pos"], refk["pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ak["vel"], refk["vel"], rtol=1e-4, atol=1e-5)
+    assert t2.simulation_step_ns() == rdtk and stats[-1]["divergence_iterations"] == rstk["divergence_iterations"]
+    info = m.info()
+    assert info["rebalances"] >= 3, info          # the skewed cuts were moved
+    assert info["halo_now"] < info["halo_max"], info  # Id = Iv = 1: the band in use is narrower than the widest one
+    assert info["exchanges"] >= steps + 1, info
+    assert info["owned_local"] == n and info["build_particles"] > n  # owned + ghosts
+    kbar_tiles = info["neighbor_entries"] / info["build_particles"]
+    assert abs(kbar_tiles - kbar_single) < 0.15, (kbar_tiles, kbar_single)  # (ghosts at the rim of the band have shorter lists)
+    assert 0 < info["remote_entries"] < info["neighbor_entries"]
+    m.close()

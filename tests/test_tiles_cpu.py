@@ -351,6 +351,165 @@ def test_shm_allreduce_four_processes():
             assert got[r][it] == want
 
 
+def _shm_victim_worker(rank, world, name, q, die_at, mode):
+    """Ranks run all-reduce rounds; rank 1 stops arriving at round `die_at` (mode "kill": the process dies without a word;
+    "abort": it reports its failure with sphx_shm_abort; "close": it closes the segment and leaves)."""
+    import ctypes as C
+    import time
+
+    os.environ["SPHX_SHM_TIMEOUT_S"] = "2"
+    from yasph2d_amd import _lib
+
+    L = _lib.lib()
+    h = L.sphx_shm_open(name.encode(), rank, world)
+    assert h
+    buf_in, buf_out = (C.c_double * 8)(), (C.c_double * 8)()
+    for it in range(1000):
+        if rank == 1 and it == die_at:
+            if mode == "kill":
+                os._exit(17)
+            if mode == "abort":
+                L.sphx_shm_abort(h)
+                q.put((rank, "aborted", it, 0.0))
+                return
+            L.sphx_shm_close(h)
+            q.put((rank, "closed", it, 0.0))
+            return
+        buf_in[0] = float(it)
+        t0 = time.perf_counter()
+        rc = L.sphx_shm_allreduce(h, buf_in, 1, 0, buf_out)
+        if rc:
+            q.put((rank, "error %d" % rc, it, time.perf_counter() - t0))
+            L.sphx_shm_close(h)
+            return
+        assert buf_out[0] == float(it) * world
+    q.put((rank, "finished", 1000, 0.0))
+
+
+@pytest.mark.parametrize("mode", ["kill", "abort", "close"])
+def test_shm_allreduce_survives_a_lost_rank(mode):
+    """One of four ranks stops arriving mid-run: the others get SPHX_ERR_NOT_READY from the very round it missed — after the
+    time-out when it was killed, at once when it said so — instead of hanging."""
+    import multiprocessing as mp
+
+    from yasph2d_amd import _lib
+
+    ctx = mp.get_context("spawn")
+    world, name, die_at = 4, f"pytestlost{os.getpid()}{mode}", 137
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shm_victim_worker, args=(r, world, name, q, die_at, mode)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(world - (1 if mode == "kill" else 0)):
+        r, what, it, waited = q.get(timeout=60)
+        got[r] = (what, it, waited)
+    for p in ps:
+        p.join(30)
+    assert ps[1].exitcode == (17 if mode == "kill" else 0)
+    for r in (0, 2, 3):
+        what, it, waited = got[r]
+        assert what == "error %d" % _lib.ERR_NOT_READY and it == die_at, got
+        assert waited < (4.0 if mode == "kill" else 1.0), got  # time-out 2 s / released at once
+        assert ps[r].exitcode == 0
+
+
+def _shm_stale_worker(rank, world, name, q, delay):
+    import ctypes as C
+    import time
+
+    os.environ["SPHX_SHM_TIMEOUT_S"] = "20"
+    from yasph2d_amd import _lib
+
+    time.sleep(delay)
+    L = _lib.lib()
+    h = L.sphx_shm_open(name.encode(), rank, world)
+    assert h
+    a, b = (C.c_double * 8)(), (C.c_double * 8)()
+    a[0] = rank + 1.0
+    rc = L.sphx_shm_allreduce(h, a, 1, 0, b)
+    L.sphx_shm_close(h)
+    q.put((rank, rc, b[0]))
+
+
+def test_shm_open_ignores_a_stale_segment():
+    """A segment a crashed run left under the same name (valid magic, old arrivals) must not capture the ranks that get there before
+    rank 0 has replaced it (ADVICE r02: RcclComm::open could put ranks on different segments)."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    name = f"pyteststale{os.getpid()}"
+    # a complete earlier "run" whose rank 0 never unlinked: world 1, then the file is left behind on purpose
+    import ctypes as C
+
+    from yasph2d_amd import _lib
+
+    L = _lib.lib()
+    h = L.sphx_shm_open(name.encode(), 0, 1)
+    assert h
+    a, b = (C.c_double * 8)(), (C.c_double * 8)()
+    for _ in range(5):
+        assert L.sphx_shm_allreduce(h, a, 1, 0, b) == 0
+    # (no sphx_shm_close: the segment stays in /dev/shm like after a crash)
+    assert os.path.exists("/dev/shm/sphx_" + name)
+    try:
+        world = 3
+        q = ctx.Queue()
+        # ranks 1 and 2 arrive first and find the stale segment; rank 0 comes a second later
+        ps = [ctx.Process(target=_shm_stale_worker, args=(r, world, name, q, 1.0 if r == 0 else 0.0)) for r in range(world)]
+        for p in ps:
+            p.start()
+        got = dict((r, (rc, v)) for r, rc, v in (q.get(timeout=60) for _ in range(world)))
+        for p in ps:
+            p.join(30)
+            assert p.exitcode == 0
+        assert all(got[r] == (0, 6.0) for r in range(world)), got
+    finally:
+        if os.path.exists("/dev/shm/sphx_" + name):
+            os.unlink("/dev/shm/sphx_" + name)
+
+
+def _rccl_bringup_worker(rank, world, job, q, env):
+    import ctypes as C
+    import time
+
+    os.environ.update(env)
+    os.environ["SPHX_SHM_TIMEOUT_S"] = "20"
+    import yasph2d_amd as y
+    from yasph2d_amd import _lib
+
+    L = _lib.lib()
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    rc = L.sphx_multi_create_rank(C.byref(y.default_params()), 0, None, job.encode(), rank, world, None, C.byref(h))
+    q.put((rank, rc, L.sphx_multi_last_error(None).decode(), time.perf_counter() - t0))
+
+
+def test_builtin_transport_fails_on_every_rank_when_one_rank_cannot_load_rccl():
+    """A rank that cannot bring RCCL up must not leave the others inside ncclCommInitRank or the shared-memory barrier: every
+    rank returns an error, promptly, with a message that says what happened.  Runs without a GPU: the
+    failure is injected before anything touches the device."""
+    import multiprocessing as mp
+
+    from yasph2d_amd import _lib
+
+    ctx = mp.get_context("spawn")
+    world, job = 3, f"pytestrccl{os.getpid()}"
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rccl_bringup_worker, args=(r, world, job, q, {"SPHX_TEST_FAIL_RCCL_LOAD": "1"})) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {r: (rc, msg, t) for r, rc, msg, t in (q.get(timeout=120) for _ in range(world))}
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(got[r][0] == _lib.ERR_HIP for r in range(world)), got
+    assert "injected" in got[1][1], got
+    for r in (0, 2):
+        assert "other rank(s) failed" in got[r][1] and "librccl" in got[r][1], got
+    assert max(t for _, _, t in got.values()) < 15.0, got
+
+
 def test_rebalance_cuts_invariants_random():
     """Whatever the loads: cuts stay strictly increasing with the outer ones fixed, no cut moves further than max_shift, interior
     tiles keep two halo widths (+2), and the function is a pure function of its inputs."""

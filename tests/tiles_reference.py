@@ -217,14 +217,10 @@ class ShmComm(TorchComm):
     def __init__(self, dist, device, name):
         super().__init__(dist, device)
         self.L = _lib.lib()
-        # rank 0 replaces any stale segment of that name before the others attach
-        self.h = self.L.sphx_shm_open(str(name).encode(), 0, self.world) if self.rank == 0 else None
-        dist.barrier()
-        if self.rank != 0:
-            self.h = self.L.sphx_shm_open(str(name).encode(), self.rank, self.world)
+        # collective: rank 0 replaces any stale segment of that name, the call returns when every rank has joined the new one
+        self.h = self.L.sphx_shm_open(str(name).encode(), self.rank, self.world)
         if not self.h:
             raise RuntimeError("sphx_shm_open failed")
-        dist.barrier()
         self._in = (C.c_double * 8)()
         self._out = (C.c_double * 8)()
 

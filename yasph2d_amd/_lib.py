@@ -86,16 +86,19 @@ class SphxMultiOptions(C.Structure):
 
 COMM_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p)
 COMM_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double))
+COMM_ABORT = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class SphxCommOps(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("exchange", COMM_EXCHANGE), ("allreduce", COMM_ALLREDUCE)]
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("exchange", COMM_EXCHANGE), ("allreduce", COMM_ALLREDUCE),
+                ("abort", COMM_ABORT)]
 
 
 class SphxMultiInfo(C.Structure):
     _fields_ = [("world", C.c_uint32), ("local_tiles", C.c_uint32), ("halo_now", C.c_uint32), ("halo_max", C.c_uint32), ("peers", C.c_uint32),
                 ("n_local", C.c_uint32), ("cap_records", C.c_uint32), ("grid_layout", C.c_uint32), ("axis", C.c_int32), ("reserved", C.c_uint32),
-                ("exchanges", C.c_uint64), ("rebalances", C.c_uint64), ("transport", C.c_char * 96)]
+                ("exchanges", C.c_uint64), ("rebalances", C.c_uint64), ("build_particles", C.c_uint64), ("neighbor_entries", C.c_uint64),
+                ("remote_entries", C.c_uint64), ("owned_local", C.c_uint64), ("transport", C.c_char * 96)]
 
 
 LAYOUT_AUTO, LAYOUT_STRIPS, LAYOUT_GRID = 0, 1, 2
@@ -147,6 +150,8 @@ SIGNATURES = {
     "sphx_sub_advect": (_i, [_vp, _f]),
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sphx_shm_abort": (None, [_vp]),
+    "sphx_build_stats": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_shm_close": (None, [_vp]),
     "sphx_tile_configure_rect": (_i, [_vp, _vp, _u32, _vp, _u32]),
     "sphx_tile_pack_n": (_i, [_vp, _vp, _u32, _u32]),

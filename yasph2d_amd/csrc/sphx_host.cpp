@@ -10,8 +10,11 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 namespace sph {
 
@@ -343,11 +346,28 @@ void HipDfsphMultiSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm
         last_error = sphx_multi_last_error(multi_);
     };
     int rc;
-    const size_t n = w.particles.positions.size();
+    size_t n = w.particles.positions.size();
     if (w.boundary_changed || n != uploaded_n_ || w.fluid_generation != uploaded_generation_) {
         // the tiles are cut from the scene: a changed boundary or particle set means a fresh decomposition
         if (w.stale_prefix) {
-            if ((rc = sync_world(w))) return fail(rc);  // headless steps left the host arrays behind: fetch them before re-cutting
+            // Headless steps left the first stale_prefix host particles behind the device: fetch them before re-cutting.  What the
+            // caller appended behind them since (add_fluid_rect mid-run) is kept: the download replaces the prefix only, like the
+            // single-context solver does.
+            const size_t keep = w.stale_prefix;
+            if (keep > n || keep != sphx_multi_num_owned(multi_)) {
+                last_status = SPHX_ERR_NOT_READY;
+                last_error = "the host world was edited while it was behind the device state: call sync_world() before editing particles";
+                return;
+            }
+            if (w.particles.velocities.size() != n) w.particles.velocities.resize(n, Vector{0, 0});
+            const std::vector<Point> tail_p(w.particles.positions.begin() + keep, w.particles.positions.end());
+            const std::vector<Vector> tail_v(w.particles.velocities.begin() + keep, w.particles.velocities.end());
+            if ((rc = sync_world(w))) return fail(rc);  // (resizes the arrays to the owned particles)
+            w.particles.positions.insert(w.particles.positions.end(), tail_p.begin(), tail_p.end());
+            w.particles.velocities.insert(w.particles.velocities.end(), tail_v.begin(), tail_v.end());
+            w.particles.densities.resize(w.particles.positions.size(), 0.0f);
+            w.particles.particle_ids.clear();  // the upload below numbers the particles afresh
+            n = w.particles.positions.size();
         }
         const auto& b = w.particles.boundary_particles;
         if ((rc = sphx_multi_set_boundary(multi_, b.empty() ? nullptr : &b[0].x, (uint32_t)b.size()))) return fail(rc);
@@ -578,13 +598,36 @@ struct ShmSegment {
     std::atomic<uint32_t> magic;
     std::atomic<uint32_t> attached;
     std::atomic<uint64_t> arrive;  // total arrivals over all epochs
+    // a rank that fails (or closes) raises this; the ranks spinning in an all-reduce return at once instead of waiting for the time-out
+    std::atomic<uint32_t> abort;
+    std::atomic<uint32_t> go;  // rank 0: every rank of THIS run has joined THIS segment
+    // join handshake: rank r publishes a random token, rank 0 echoes it.  A segment a crashed earlier run left under the same name
+    // has nobody echoing: a rank that got there before rank 0 replaced it notices and attaches again.
+    std::atomic<uint64_t> token[SHM_MAX_WORLD], echo[SHM_MAX_WORLD];
     double slots[2][SHM_MAX_WORLD][SHM_MAX_N];
 };
+double shm_timeout_s() {  // SPHX_SHM_TIMEOUT_S: how long an all-reduce waits for a rank that never arrives (default 300 s; tests: 2)
+    if (const char* e = std::getenv("SPHX_SHM_TIMEOUT_S")) {
+        const double v = std::atof(e);
+        if (v > 0) return v;
+    }
+    return 300.0;
+}
+uint64_t shm_random_token() {
+    uint64_t t = 0;
+    if (FILE* f = std::fopen("/dev/urandom", "rb")) {
+        if (std::fread(&t, sizeof(t), 1, f) != 1) t = 0;
+        std::fclose(f);
+    }
+    t ^= (uint64_t)getpid() << 32 ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    return t ? t : 1;
+}
 }  // namespace
 struct sphx_shm {
     ShmSegment* seg = nullptr;
     int rank = 0, world = 1;
     uint64_t epoch = 0;
+    double timeout_s = 300.0;
     std::string name;
 };
 
@@ -592,55 +635,123 @@ extern "C" {
 
 sphx_shm* sphx_shm_open(const char* name, int rank, int world) {
     if (!name || rank < 0 || world < 1 || rank >= world || world > SHM_MAX_WORLD) return nullptr;
-    std::string nm = std::string("/sphx_") + name;
-    int fd = -1;
-    if (rank == 0) {
-        shm_unlink(nm.c_str());
-        fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, sizeof(ShmSegment)) != 0) {
-            if (fd >= 0) close(fd);
-            return nullptr;
-        }
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while ((fd = shm_open(nm.c_str(), O_RDWR, 0600)) < 0) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return nullptr;
-            std::this_thread::sleep_for(std::chrono::milliseconds(5));
-        }
-        struct stat st;
-        while (fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(ShmSegment)) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-                close(fd);
-                return nullptr;
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(5));
-        }
-    }
-    void* p = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return nullptr;
+    const std::string nm = std::string("/sphx_") + name;
+    const double join_timeout = std::min(shm_timeout_s(), 120.0);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > join_timeout; };
+    auto map = [&](int fd) -> ShmSegment* {
+        void* p = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        return p == MAP_FAILED ? nullptr : (ShmSegment*)p;
+    };
     sphx_shm* h = new sphx_shm();
-    h->seg = (ShmSegment*)p;
     h->rank = rank;
     h->world = world;
     h->name = nm;
+    h->timeout_s = shm_timeout_s();
     if (rank == 0) {
-        h->seg->arrive.store(0);
-        h->seg->attached.store(0);
+        shm_unlink(nm.c_str());  // whatever an earlier run left under this name is not ours
+        const int fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(ShmSegment)) != 0) {  // (a fresh segment is zero-filled: no tokens, no arrivals)
+            if (fd >= 0) close(fd);
+            delete h;
+            return nullptr;
+        }
+        h->seg = map(fd);
+        close(fd);
+        if (!h->seg) {
+            delete h;
+            return nullptr;
+        }
         h->seg->magic.store(0x53504858u, std::memory_order_release);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (h->seg->magic.load(std::memory_order_acquire) != 0x53504858u) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-                munmap(p, sizeof(ShmSegment));
+        // echo every rank's token as it appears
+        int joined = 1;
+        std::vector<uint8_t> seen(world, 0);
+        while (joined < world) {
+            for (int r = 1; r < world; ++r) {
+                const uint64_t t = h->seg->token[r].load(std::memory_order_acquire);
+                if (t && !seen[r]) {
+                    h->seg->echo[r].store(t, std::memory_order_release);
+                    seen[r] = 1;
+                    joined += 1;
+                }
+            }
+            if (joined < world) {
+                if (late()) {
+                    munmap(h->seg, sizeof(ShmSegment));
+                    shm_unlink(nm.c_str());
+                    delete h;
+                    return nullptr;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
+        h->seg->attached.store((uint32_t)world);
+        h->seg->go.store(1, std::memory_order_release);
+        return h;
+    }
+    const uint64_t my_token = shm_random_token();
+    for (;;) {  // attach; if nobody echoes the token the segment is a stale one: attach again
+        int fd = -1;
+        while ((fd = shm_open(nm.c_str(), O_RDWR, 0600)) < 0) {
+            if (late()) {
                 delete h;
                 return nullptr;
             }
-            std::this_thread::yield();
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
         }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(ShmSegment)) {
+            // rank 0 has created the file but not sized it yet — or this is a leftover of another layout: look the name up again
+            close(fd);
+            if (late()) {
+                delete h;
+                return nullptr;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            continue;
+        }
+        const ino_t ino = st.st_ino;
+        ShmSegment* seg = map(fd);
+        close(fd);
+        if (!seg) {
+            delete h;
+            return nullptr;
+        }
+        bool stale = false;
+        while (seg->magic.load(std::memory_order_acquire) != 0x53504858u && !late()) std::this_thread::yield();
+        seg->token[rank].store(my_token, std::memory_order_release);
+        auto t_check = std::chrono::steady_clock::now();
+        while (!(seg->echo[rank].load(std::memory_order_acquire) == my_token && seg->go.load(std::memory_order_acquire))) {
+            if (late()) {
+                munmap(seg, sizeof(ShmSegment));
+                delete h;
+                return nullptr;
+            }
+            if (std::chrono::steady_clock::now() - t_check > std::chrono::milliseconds(20)) {
+                // does the name still lead to the segment that is mapped here?
+                t_check = std::chrono::steady_clock::now();
+                const int fd2 = shm_open(nm.c_str(), O_RDWR, 0600);
+                struct stat st2;
+                const bool same = fd2 >= 0 && fstat(fd2, &st2) == 0 && st2.st_ino == ino;
+                if (fd2 >= 0) close(fd2);
+                if (!same) {
+                    stale = true;
+                    break;
+                }
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (stale) {
+            munmap(seg, sizeof(ShmSegment));
+            continue;
+        }
+        h->seg = seg;
+        return h;
     }
-    h->seg->attached.fetch_add(1);
-    return h;
+}
+
+void sphx_shm_abort(sphx_shm* h) {
+    if (h && h->seg) h->seg->abort.store(1, std::memory_order_release);
 }
 
 int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out) {
@@ -654,7 +765,15 @@ int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
     while (s->arrive.load(std::memory_order_acquire) < target) {
-        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) return SPHX_ERR_NOT_READY;
+        if (s->abort.load(std::memory_order_acquire)) {
+            // (a rank that has finished raises the word when it closes: everybody had arrived by then — look again before giving up)
+            if (s->arrive.load(std::memory_order_acquire) >= target) break;
+            return SPHX_ERR_NOT_READY;
+        }
+        if ((++spins & 0x3FFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->timeout_s) {
+            s->abort.store(1, std::memory_order_release);  // nobody else needs to sit out the same time-out
+            return SPHX_ERR_NOT_READY;
+        }
         __builtin_ia32_pause();
     }
     for (int k = 0; k < n; ++k) {
@@ -671,6 +790,7 @@ int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out
 void sphx_shm_close(sphx_shm* h) {
     if (!h) return;
     if (h->seg) {
+        h->seg->abort.store(1, std::memory_order_release);  // whoever still waits for this rank will not get it
         munmap(h->seg, sizeof(ShmSegment));
         if (h->rank == 0) shm_unlink(h->name.c_str());
     }

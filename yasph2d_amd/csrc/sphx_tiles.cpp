@@ -145,6 +145,7 @@ struct Comm {
     // send[k] -> peers[k], recv[k] <- peers[k]; `bytes` of each buffer; ordered on the tile's stream (no host synchronisation)
     virtual int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) = 0;
     virtual int allreduce(const double* in, int n, int op, double* out) = 0;  // op 0 sum, 1 max; same bits on every rank
+    virtual void abort() {}  // this tile has failed: the tiles waiting for it in an all-reduce are released (they fail too)
     virtual const char* name() const = 0;
 };
 
@@ -160,6 +161,9 @@ struct CallbackComm : Comm {
         return ops.exchange(ops.user, peers.data(), (int)peers.size(), send.data(), recv.data(), bytes, (void*)st);
     }
     int allreduce(const double* in, int n, int op, double* out) override { return ops.allreduce(ops.user, in, n, op, out); }
+    void abort() override {
+        if (ops.abort) ops.abort(ops.user);
+    }
     const char* name() const override { return "caller-supplied communicator"; }
 };
 
@@ -193,26 +197,46 @@ struct RcclComm : Comm {
         }
         const char* always = std::getenv("SPHX_RCCL_ALWAYS");  // test aid: bring RCCL up even for a single rank
         if (world == 1 && !(always && always[0] == '1')) return SPHX_OK;  // nothing to exchange
+        // Every step of the bring-up ends in a status round over the shared segment: a rank that cannot go on says so, and ALL ranks
+        // return an error together — nobody is left inside ncclCommInitRank (or the first all-reduce) waiting for a rank that gave up.
+        auto agree = [&](bool ok, const char* stage) -> bool {
+            double in = ok ? 0.0 : 1.0, out = 0.0;
+            if (sphx_shm_allreduce(shm, &in, 1, 0, &out) != SPHX_OK) {
+                if (ok || err.empty()) err = std::string("a rank did not reach the status round after: ") + stage;
+                return false;
+            }
+            if (out > 0.0) {
+                if (ok) err = std::to_string((int)out) + " other rank(s) failed: " + stage;
+                return false;
+            }
+            return true;
+        };
         for (const char* n : {"librccl.so", "librccl.so.1"}) {
             lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
-        if (!lib) {
-            err = std::string("dlopen(librccl.so): ") + dlerror();
-            return SPHX_ERR_HIP;
+        bool ok = lib != nullptr;
+        if (!lib) err = std::string("dlopen(librccl.so): ") + dlerror();
+        if (ok) {
+            p_get_uid = (int (*)(Uid*))dlsym(lib, "ncclGetUniqueId");
+            p_init = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
+            p_destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+            p_send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclSend");
+            p_recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclRecv");
+            p_gstart = (int (*)())dlsym(lib, "ncclGroupStart");
+            p_gend = (int (*)())dlsym(lib, "ncclGroupEnd");
+            p_err = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+            if (!p_get_uid || !p_init || !p_send || !p_recv || !p_gstart || !p_gend) {
+                err = "librccl.so lacks the ncclSend/ncclRecv entry points";
+                ok = false;
+            }
         }
-        p_get_uid = (int (*)(Uid*))dlsym(lib, "ncclGetUniqueId");
-        p_init = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
-        p_destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
-        p_send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclSend");
-        p_recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclRecv");
-        p_gstart = (int (*)())dlsym(lib, "ncclGroupStart");
-        p_gend = (int (*)())dlsym(lib, "ncclGroupEnd");
-        p_err = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
-        if (!p_get_uid || !p_init || !p_send || !p_recv || !p_gstart || !p_gend) {
-            err = "librccl.so lacks the ncclSend/ncclRecv entry points";
-            return SPHX_ERR_HIP;
-        }
+        if (const char* f = std::getenv("SPHX_TEST_FAIL_RCCL_LOAD"))  // test aid: this rank pretends librccl is missing
+            if (std::atoi(f) == rank) {
+                err = "librccl.so: load failure injected by SPHX_TEST_FAIL_RCCL_LOAD";
+                ok = false;
+            }
+        if (!agree(ok, "loading librccl.so")) return SPHX_ERR_HIP;
         Uid id;
         std::memset(&id, 0, sizeof(id));
         int rc = 0;
@@ -226,22 +250,29 @@ struct RcclComm : Comm {
             if (sphx_shm_allreduce(shm, in, 8, 0, out)) rc = -1;
             for (int k = 0; k < 8; ++k) id.b[part * 8 + k] = (char)(unsigned char)out[k];
         }
-        if (rc) {
-            err = "broadcast of the RCCL unique id failed";
-            return SPHX_ERR_HIP;
-        }
-        if (hipSetDevice(device) != hipSuccess) {
+        ok = rc == 0;
+        if (!ok) err = "ncclGetUniqueId / broadcast of the RCCL unique id failed";
+        if (ok && hipSetDevice(device) != hipSuccess) {
             err = "hipSetDevice";
-            return SPHX_ERR_HIP;
+            ok = false;
         }
+        if (!agree(ok, "unique id / device selection")) return SPHX_ERR_HIP;
         rc = p_init(&comm, world, id, rank);
+        if (const char* f = std::getenv("SPHX_TEST_FAIL_RCCL_INIT"))  // test aid: this rank reports a failed ncclCommInitRank
+            if (std::atoi(f) == rank && !rc) rc = 1;
         if (rc) {
             err = std::string("ncclCommInitRank: ") + (p_err ? p_err(rc) : "error");
+            if (comm && p_destroy && rc == 1 && std::getenv("SPHX_TEST_FAIL_RCCL_INIT")) p_destroy(comm);
+            comm = nullptr;
+        }
+        if (!agree(rc == 0, "ncclCommInitRank")) {
+            if (comm && p_destroy) p_destroy(comm);
             comm = nullptr;
             return SPHX_ERR_HIP;
         }
         return SPHX_OK;
     }
+    void abort() override { sphx_shm_abort(shm); }
     ~RcclComm() override {
         if (comm && p_destroy) p_destroy(comm);
         if (shm) sphx_shm_close(shm);
@@ -358,6 +389,7 @@ struct LocalComm : Comm {
         if (!sh->barrier()) return SPHX_ERR_NOT_READY;
         return SPHX_OK;
     }
+    void abort() override { sh->abort(); }
     const char* name() const override { return "in-process tiles (peer copies ordered by HIP events)"; }
 };
 
@@ -396,11 +428,18 @@ struct TileDriver {
     float pending_advect_dt = 0.0f;
     bool overlap = false;  // sphx_multi_options.overlap_exchange / SPHX_MULTI_OVERLAP=1: records on a second stream, interior work meanwhile
 
+    bool poisoned = false;  // a collective step failed half-way: receives that will never complete may sit on the stream
     int fail(int rc, const std::string& what) {
         err = what;
         if (ctx && rc != SPHX_OK) {
             const char* e = sphx_last_error(ctx);
             if (e && *e) err += std::string(": ") + e;
+        }
+        if (rc != SPHX_OK && comm && comm->world > 1) {
+            // the other tiles are (or will be) waiting for this one in an all-reduce: release them — they fail with NOT_READY at
+            // once instead of sitting out the time-out (or, over RCCL, a receive nobody will ever send)
+            comm->abort();
+            poisoned = true;
         }
         return rc;
     }
@@ -411,6 +450,12 @@ struct TileDriver {
     } while (0)
 
     ~TileDriver() {
+        if (ctx && poisoned && comm && comm->world > 1 && std::string(comm->name()).find("in-process") == std::string::npos) {
+            // one process per tile and the run has failed: a queued receive may never complete — do not wait for the stream, the
+            // process is about to report the error and exit
+            ctx = nullptr;
+            return;
+        }
         if (ctx) {
             hipSetDevice(device);
             sphx_synchronize(ctx);
@@ -1111,6 +1156,15 @@ int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out) {
     out->cap_records = t.cap;
     out->grid_layout = t.layout.axis < 0;
     out->axis = t.layout.axis;
+    for (auto& tp : m->tiles) {
+        uint32_t np = 0;
+        uint64_t ne = 0, nr = 0;
+        sphx_build_stats(tp->ctx, &np, &ne, &nr);
+        out->build_particles += np;
+        out->neighbor_entries += ne;
+        out->remote_entries += nr;
+        out->owned_local += tp->n_owned_local;
+    }
     std::snprintf(out->transport, sizeof(out->transport), "%s", t.comm->name());
     return SPHX_OK;
 }

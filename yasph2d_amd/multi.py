@@ -30,16 +30,13 @@ class TorchCommOps:
         self.L = _lib.lib()
         self.shm = None
         if shm_name is not None:
-            self.shm = self.L.sphx_shm_open(str(shm_name).encode(), 0, self.world) if self.rank == 0 else None
-            dist.barrier()
-            if self.rank != 0:
-                self.shm = self.L.sphx_shm_open(str(shm_name).encode(), self.rank, self.world)
+            self.shm = self.L.sphx_shm_open(str(shm_name).encode(), self.rank, self.world)  # collective: returns when all ranks have joined
             if not self.shm:
                 raise RuntimeError("sphx_shm_open failed")
-            dist.barrier()
         self._ex = _lib.COMM_EXCHANGE(self._exchange)
         self._ar = _lib.COMM_ALLREDUCE(self._allreduce)
-        self.ops = _lib.SphxCommOps(None, self.rank, self.world, self._ex, self._ar)
+        self._ab = _lib.COMM_ABORT(self._abort)
+        self.ops = _lib.SphxCommOps(None, self.rank, self.world, self._ex, self._ar, self._ab)
         self.error = None
 
     def _tensor(self, ptr, nbytes):
@@ -86,6 +83,10 @@ class TorchCommOps:
         except BaseException as e:  # noqa: BLE001
             self.error = e
             return _lib.ERR_HIP
+
+    def _abort(self, user):
+        if self.shm:  # (torch.distributed has no abort: its collectives run into their own time-out)
+            self.L.sphx_shm_abort(self.shm)
 
     def close(self):
         if self.shm:
