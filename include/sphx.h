@@ -233,6 +233,18 @@ int sphx_sub_regrid_div(sphx_ctx* ctx, uint32_t* out_n_local);
 /* The other case: the divergence loop that follows starts WITH a warm start (dfsph.rs:354-360); the neighbour build applies it, and
  * the sphx_sub_warmstart(divergence = 1) call that follows returns without launching anything. */
 int sphx_sub_regrid_warm(sphx_ctx* ctx, uint32_t* out_n_local);
+/* The tile loop's run-ahead over the step boundary: arms the NEXT sphx_sub_iteration to queue the next step's non-pressure pass (with
+ * dt_prev = dt_prev_of_next_step) and the publish of its maximum behind its own kernels; the next sphx_sub_nonpressure with the same
+ * dt_prev adopts the result if nothing has touched the context in between, and simply runs again otherwise. */
+int sphx_sub_run_ahead(sphx_ctx* ctx, float dt_prev_of_next_step);
+/* Tile mode: which warm-start arrays (warmstart_kappa, warmstart_stiffness) the re-grids move with their particles (default: both).
+ * An array the next solver loop zeroes before it reads it (no warm start: dfsph.rs:199 / :354) need not travel. */
+int sphx_tile_carry_warmstart(sphx_ctx* ctx, int kappa, int stiffness);
+/* Tile mode, for callers that run sphx_tile_advect_pack_n -> exchange -> sphx_tile_apply_n -> sphx_sub_regrid* back to back: the packing
+ * pass classifies, counts and sends the advected particles but leaves the records of the particles the tile keeps to the re-grid's
+ * gather, which applies the same x += v* dt while it moves them (24 bytes per particle less in the packing pass).  Any other entry
+ * point that looks at the records in between applies the pending advection first. */
+int sphx_tile_defer_advect(sphx_ctx* ctx, int on);
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */

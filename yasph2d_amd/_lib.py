@@ -151,6 +151,9 @@ SIGNATURES = {
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
     "sphx_shm_abort": (None, [_vp]),
+    "sphx_sub_run_ahead": (_i, [_vp, C.c_float]),
+    "sphx_tile_carry_warmstart": (_i, [_vp, _i, _i]),
+    "sphx_tile_defer_advect": (_i, [_vp, _i]),
     "sphx_build_stats": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_shm_close": (None, [_vp]),
     "sphx_tile_configure_rect": (_i, [_vp, _vp, _u32, _vp, _u32]),

@@ -266,7 +266,16 @@ struct sphx_ctx {
         bool queued = false;  // the pass is on the stream and has consumed vmax slot `vslot`
         bool valid = false;   // ... and nothing has invalidated what it read
         uint32_t n = 0, dt_bits = 0, vslot = 0;
+        uint32_t seq = 0;     // sub-step API (tiles): mailbox sequence number its maximum is published under (0: not published yet)
     } ahead;
+    // tile path: the packing pass has classified, counted and sent the ADVECTED particles but left the records of the first
+    // tile_pending_n particles where they were: the re-grid's gather applies x += v* dt while it moves them (flush_pending_advect
+    // does it on the spot for anybody who looks at the records before that)
+    float tile_pending_dt = 0.0f;
+    uint32_t tile_pending_n = 0;
+    bool tile_defer_advect = false;  // sphx_tile_defer_advect
+    float sub_ahead_dt = 0.0f;  // sphx_sub_run_ahead: the next sphx_sub_iteration queues the next step's non-pressure pass behind its kernels
+    bool tile_carry_kappa = true, tile_carry_stiff = true;  // sphx_tile_carry_warmstart: which warm-start arrays the re-grid's gather moves
     int run_ahead = 1;
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it

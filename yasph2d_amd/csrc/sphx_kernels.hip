@@ -556,6 +556,7 @@ struct GatherArgs {
     DevScalars* count_owned;  // tile mode: counts ids with bit 31 set
     DevScalars* flags;        // DF_DENSE_CELL goes here
     float advect_dt;          // > 0: the fluid build inside a step — positions advance by v*dt while the records move
+    uint32_t advect_below;    // ... for the records with a previous index below this (tile path: the arrivals behind them are already advected)
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     if (dst >= n) return;
     if (a.pv_in) {
         float4 pv = a.pv_in[i];
-        if (a.advect_dt > 0.0f) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
+        if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
             pv.x = pv.x + pv.z * a.advect_dt;
             pv.y = pv.y + pv.w * a.advect_dt;
         }
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ bl
 __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
                                                     uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt, CountArgs ca,
-                                                    DevScalars* __restrict__ scal) {
+                                                    DevScalars* __restrict__ scal, uint32_t write_back) {
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -743,7 +744,9 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
         pv = tile_advected(PV[i], dt);
         id = pid[i];
         m = tile_send_mask(K, P, halo, pv, id);
-        if (dt > 0.0f) {  // fused advection: the record moves on
+        // fused advection: the record moves on — unless the re-grid's gather is going to apply the same two operations while it moves
+        // the record anyway (write_back = 0: 24 bytes per particle less in this pass)
+        if (dt > 0.0f && write_back) {
             PV[i] = pv;
             posA[i] = make_float2(pv.x, pv.y);
         }
@@ -1483,7 +1486,11 @@ __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
         wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads
     }
 #pragma unroll
+#ifdef SPHX_ABL_NOREMOTE  // (traffic experiments: the out-of-window records are NOT fetched — results are wrong)
+    for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(h.lw0);
+#else
     for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
+#endif
 #pragma unroll
     for (uint32_t u = 0; u < NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;

@@ -427,6 +427,7 @@ struct TileDriver {
     bool in_step = false;
     float pending_advect_dt = 0.0f;
     bool overlap = false;  // sphx_multi_options.overlap_exchange / SPHX_MULTI_OVERLAP=1: records on a second stream, interior work meanwhile
+    bool run_ahead_ok = true;  // SPHX_RUN_AHEAD=0 switches the run-ahead over the step boundary off (A/B runs)
 
     bool poisoned = false;  // a collective step failed half-way: receives that will never complete may sit on the stream
     int fail(int rc, const std::string& what) {
@@ -480,6 +481,7 @@ struct TileDriver {
         comm = std::move(c);
         overlap = O.overlap_exchange != 0;
         if (const char* e = std::getenv("SPHX_MULTI_OVERLAP")) overlap = e[0] == '1';
+        if (const char* e = std::getenv("SPHX_RUN_AHEAD")) run_ahead_ok = e[0] != '0';
         halo_max = O.halo_cells ? O.halo_cells : 16;
         min_halo = std::min<uint32_t>(6, halo_max);
         halo_now = halo_max;
@@ -494,6 +496,7 @@ struct TileDriver {
             return fail(SPHX_ERR_HIP, "hipStreamCreate / hipEventCreate");
         // the tile's kernels and its communication share one stream: pack -> exchange -> unpack are ordered by the stream
         TCHK(sphx_set_stream(ctx, stream));
+        TCHK(sphx_tile_defer_advect(ctx, overlap ? 0 : 1));  // (with the exchange on a second stream the kept particles are counted from their records)
         bufs.assign(comm->world, {nullptr, nullptr});
         return SPHX_OK;
     }
@@ -743,6 +746,13 @@ struct TileDriver {
             const double kv = std::min(valid - 1, avalid);
             double s = 0;
             uint64_t owned = 0;
+            // Run-ahead over the step boundary: if this is the iteration the divergence loop is expected to end with (the count of the
+            // previous step), and the ghost band still has a ring for it, the NEXT step's non-pressure pass goes onto the stream behind
+            // it — the GPU works on it while the residual makes its round trip through the hosts' all-reduce, and the maximum is in the
+            // mailbox when the next step asks for it.  A loop that goes on invalidates the pass (it simply runs again).
+            if (divergence && run_ahead_ok && iters + 1 == std::max<uint32_t>(1, fixed ? fixed : prev) &&
+                std::min(avalid, std::min(valid - 2, avalid - 1)) - 1 >= 0)
+                TCHK(sphx_sub_run_ahead(ctx, dt));
             TCHK(sphx_sub_iteration(ctx, divergence ? 1 : 0, dt, iters == 0, &s, &owned));
             n_owned_local = owned;
             valid = std::min(valid - 2, avalid - 1);
@@ -814,7 +824,12 @@ struct TileDriver {
             // rings of the interval that ends here: divergence loop of the previous step, non-pressure pass, this density loop, and
             // the one-ring offset of density/alpha (computed one traversal after the exchange)
             adapt_halo((int)(last_div_warm + 2 * last_div_iters + 1 + s.warmstart_density + 2 * s.density_iterations + 1));
+        // warm-start values only travel through this re-grid if a loop will read them before it zeroes them: kappa by the next step's
+        // density loop iff this one took more than one iteration (dfsph.rs:199), the stiffness by the divergence loop that follows iff
+        // the previous one did (dfsph.rs:354)
+        TCHK(sphx_tile_carry_warmstart(ctx, num_density_iters > 1, num_divergence_iters > 1));
         rc = refresh(num_divergence_iters <= 1, num_divergence_iters > 1);  // migration + ghosts, dfsph.rs:512-518 (warm start ahead <=> dfsph.rs:354)
+        TCHK(sphx_tile_carry_warmstart(ctx, 1, 1));  // (an extra exchange in the middle of a loop moves values that are in use)
         if (rc) return rc;
         rc = loop(true, dt, &s.divergence_iterations, &s.avg_divergence, &s.warmstart_divergence, &s.flags);  // dfsph.rs:521
         if (rc) return rc;
