@@ -2,7 +2,7 @@
 """profiles/<prefix>_traffic_<tag>.json from the FETCH_SIZE / WRITE_SIZE tables of tools/summarize_profile.py (separate rocprofv3
 passes of `python3 bench.py ...`).  bench.py reads it for roofline.traffic (the counters cannot be read from inside the process).
 
-usage: make_traffic_json.py fetch.txt write.txt particles out.json "source text"
+usage: make_traffic_json.py fetch.txt write.txt particles out.json "source text" [git head]
 """
 import json
 import sys
@@ -37,5 +37,8 @@ scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0) + 
         "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0) + write.get("k_scan_onepass", 0)}
 scan["total"] = scan["fetch"] + scan["write"]
 res["cell_scan"] = scan
-json.dump({"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}, open(sys.argv[4], "w"), indent=1)
+doc = {"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}
+if len(sys.argv) > 6 and sys.argv[6]:
+    doc["git_head"] = sys.argv[6]  # the build the counters were taken from (bench.py quotes it next to roofline.traffic)
+json.dump(doc, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(res, indent=1)[:400])

@@ -1286,26 +1286,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
     SPHX_STAMP_BEGIN()
     const bool live = i < n;
-    const float2 pi = posA[live ? i : b0];  // own position straight from global memory: the cell look-ups below do not wait for the barrier
+    // (scalar base + 32-bit lane offset addressing throughout — gat(): the arrays stay below 4 GiB)
+    const float2 pi = gat(posA, live ? i : b0);  // own position straight from global memory: the cell look-ups below do not wait for the barrier
     constexpr uint32_t NWIN = (WIN_SLOTS + 255) / 256;
     float2 wreg[NWIN];
 #pragma unroll
-    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = posA[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
+    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = gat(posA, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
     float2 vreg[MODE == 2 ? NWIN : 1];
     float2 vi = make_float2(0.0f, 0.0f);
     if (MODE == 2) {
         const float2* vel = (const float2*)dv.PV + 1;  // PV[k].zw = vel[2 k]
 #pragma unroll
-        for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = vel[2u * (w0 + min(threadIdx.x + u * 256u, wlen - 1u))];
-        vi = vel[2u * (live ? i : b0)];
+        for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = gat(vel, 2u * (w0 + min(threadIdx.x + u * 256u, wlen - 1u)));
+        vi = gat(vel, 2u * (live ? i : b0));
     }
     float sreg[MODE == 3 ? NWIN : 1];
     float warm_i = 0.0f;
     if (MODE == 3) {
 #pragma unroll
-        for (uint32_t u = 0; u < NWIN; ++u) sreg[u] = dv.warm[w0 + min(threadIdx.x + u * 256u, wlen - 1u)];
-        warm_i = dv.warm[live ? i : b0];
-        vi = ((const float2*)dv.PVw)[2u * (live ? i : b0) + 1u];
+        for (uint32_t u = 0; u < NWIN; ++u) sreg[u] = gat(dv.warm, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
+        warm_i = gat(dv.warm, live ? i : b0);
+        vi = gat((const float2*)dv.PVw, 2u * (live ? i : b0) + 1u);
     }
     uint32_t cx, cy;
     cell_of(K, pi, cx, cy);
