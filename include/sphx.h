@@ -14,6 +14,24 @@
  *   - one context = one caller thread at a time (mirrors `&mut self` of Solver::simulation_step, solver/mod.rs:17).
  *   - all device work runs on one HIP stream — the context's own, or the caller's (sphx_set_stream); calls that return host data
  *     synchronise it.  The only exception is the viewer feed's device-to-host copy, which has a stream of its own.
+ *
+ * What is the contract and what is scaffolding (the header has grown beyond the boundary SURVEY.md 8(b) asks for):
+ *   STABLE — the drop-in boundary a Rust shim binds:
+ *       lifecycle (sphx_default_params, sphx_create, sphx_destroy, sphx_last_error, sphx_abi_version), the particle-array
+ *       surface (sphx_set_boundary, sphx_upload, sphx_download*, sphx_num_*, sphx_view_*), the Solver trait (sphx_clear_cached,
+ *       sphx_step_begin[_law], sphx_step_finish, sphx_wcsph_step_*), the same trait over a device list (sphx_multi_create[_rank],
+ *       sphx_multi_destroy, sphx_multi_set_boundary, sphx_multi_upload, sphx_multi_clear_cached, sphx_multi_step_begin/finish,
+ *       sphx_multi_simulation_step[s], sphx_multi_download, sphx_multi_num_owned, sphx_multi_last_error, sphx_comm_ops) and
+ *       the status / flag codes.
+ *   INSPECTION — parity tests and tools, not on the hot path, may change with the data layout:
+ *       sphx_update_neighborhood, sphx_update_densities, sphx_compute_alpha (the pieces benches/ drives), sphx_download_solver_state,
+ *       sphx_download_neighbors, sphx_download_cells, sphx_grid_info, sphx_get_constants, sphx_last_flags, sphx_build_stats,
+ *       sphx_multi_info, sphx_multi_tile_ctx, sphx_multi_set_layout / _set_grid_layout, sphx_profile_*, sphx_synchronize.
+ *   INTERNAL — the seam between the tile loop (csrc/sphx_tiles.cpp) and a tile's context, exported so that the tests can drive the
+ *       same sub-steps from the reference implementation of that loop (tests/tiles_reference.py); no stability promise:
+ *       sphx_reserve, sphx_tile_*, sphx_sub_*, sphx_set_stream, sphx_shm_*.
+ *   HOST MIRROR — the C++ twin of the reference's host types (world, timer, solver object) for hosts without a Rust toolchain:
+ *       sphx_world_*, sphx_timer_*, sphx_solver_*, sphx_duration_*.
  */
 #ifndef SPHX_H
 #define SPHX_H
@@ -25,7 +43,9 @@
 extern "C" {
 #endif
 
-#define SPHX_ABI_VERSION 2 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL */
+#define SPHX_ABI_VERSION 3 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
+                            * 3: sphx_comm_ops.abort, sphx_multi_info_t list statistics, sphx_shm_abort (and sphx_shm_open as a collective),
+                            *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect */
 
 /* ---- status codes ---- */
 enum {

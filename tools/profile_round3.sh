@@ -32,7 +32,7 @@ for n in stats_1M stats_16M stats_1M_iterating_fixed32 stats_1M_iterating_window
 done
 for n in fetch_1M write_1M fetch_16M write_16M; do f=$(find $out/$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 $S $f > $out/$n.txt; done
 for n in sq_1M sq2_1M tcc_1M; do f=$(find $out/$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_table.py $f > $out/$n.txt; done
-HEAD=$(cat $GRAFT_REPO_ROOT/.git_head 2>/dev/null)
+HEAD=$(cat $GRAFT_REPO_ROOT/GIT_HEAD.txt 2>/dev/null)
 python3 tools/make_traffic_json.py $out/fetch_1M.txt $out/write_1M.txt 999698 $out/traffic_1M.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of python3 bench.py), profiles/r03_{fetch,write}_1M.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)" "$HEAD" > /dev/null
 python3 tools/make_traffic_json.py $out/fetch_16M.txt $out/write_16M.txt 15996960 $out/traffic_16M.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of python3 bench.py --particles 16000000), profiles/r03_{fetch,write}_16M.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md" "$HEAD" > /dev/null
 if [ "$2" = prof ]; then find $out -name "*.csv" -delete; find $out -type d -empty -delete; exit 0; fi
