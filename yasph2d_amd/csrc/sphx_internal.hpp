@@ -80,6 +80,11 @@ struct Consts {
 
 // wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 | entries of the
 // workgroup's out-of-window table remote[(i >> 8) * REMOTE_CAP ..] << 14 | wide << 31
+// positions + velocities of the [N|B] arrays as one read view (sphx_kernels.hip: ldpv)
+struct PVr {
+    const float2* pos;
+    const float2* vel;
+};
 struct NbView {
     const uint32_t* list;
     const uint32_t* counts;
@@ -222,8 +227,9 @@ struct sphx_ctx {
     // Particle state (device, Morton cell order).  Arrays marked [N|B] hold the fluid particles in [0, N) and the sorted
     // boundary particles as a tail at offset soff() = capN, so a neighbour index j (dynamic) or soff()+j (static) addresses
     // one array and the traversal loops need no dynamic/static branch.
-    float2 *posA = nullptr, *posA2 = nullptr;  // [N|B] positions (compact copy for the candidate scan)
-    float4 *PV = nullptr, *PV2 = nullptr;      // [N|B] {pos.x, pos.y, v.x, v.y}: v = velocity, after predict = predicted velocity
+    float2 *posA = nullptr, *posA2 = nullptr;  // [N|B] positions
+    float2 *vel = nullptr, *vel2 = nullptr;    // [N|B] velocities (boundary tail: 0); after predict = the predicted velocities (dfsph.rs:484-492)
+    sphx::PVr pv() const { return sphx::PVr{posA, vel}; }
     float* kbuf = nullptr;                     // [N] k = err * alpha of the running solver iteration: written by compute_error, staged by correct
     float2* accel = nullptr;                   // [N]
     float *density = nullptr, *alpha = nullptr, *alpha2 = nullptr, *kappa = nullptr, *stiff = nullptr;  // [N]

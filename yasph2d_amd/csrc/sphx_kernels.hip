@@ -136,6 +136,14 @@ __device__ __forceinline__ T gat(const T* __restrict__ base, uint32_t idx) {
     return *(const T*)((const char*)base + (uint32_t)(idx * (uint32_t)sizeof(T)));
 }
 
+// Positions and velocities live in two float2 arrays ([N|B], boundary tail: v = 0): the kernels that only change velocities (the
+// prediction, the four corrections) then read and write 8 bytes of their particle's record instead of 16 — writes are line-granular,
+// a half-written 16-byte record costs its full line.  A kernel that needs both halves of a record loads them as a pair.
+__device__ __forceinline__ float4 ldpv(const PVr& v, uint32_t idx) {
+    const float2 p = gat(v.pos, idx), u = gat(v.vel, idx);
+    return make_float4(p.x, p.y, u.x, u.y);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // device-wide exclusive scan (reduce / scan-partials / apply), length may live on the device
 // ------------------------------------------------------------------------------------------------------------------
@@ -510,7 +518,7 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
 // first: the pass covers particles [first, n) (the tile path counts the particles it kept while the halo exchange is in flight and
 // the received ones afterwards)
 template <bool ADVECT>
-__global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV, const float2* __restrict__ pos_in,
+__global__ __launch_bounds__(256) void k_key_count(PVr PV, const float2* __restrict__ pos_in,
                                                     uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
                                                     uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
                                                     DevScalars* __restrict__ scal, uint32_t first) {
@@ -519,8 +527,8 @@ __global__ __launch_bounds__(256) void k_key_count(const float4* __restrict__ PV
     if (i < n) {
         if (ADVECT) {
             // the advected position is only needed for the key here; k_rank_gather repeats the same two operations when it moves
-            // the record, so this pass writes neither PV nor posA (24 B per particle less)
-            const float4 pv = PV[i];
+            // the record, so this pass writes no position (16 B per particle less)
+            const float4 pv = ldpv(PV, i);
             p = make_float2(pv.x + pv.z * dt, pv.y + pv.w * dt);
         } else {
             p = pos_in[i];
@@ -541,10 +549,10 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
 }
 
 struct GatherArgs {
-    const float2* pos_in;  // boundary build: plain positions
-    float2* pos_out;       // fluid build: receives PV.xy
-    const float4* pv_in;
-    float4* pv_out;
+    const float2* pos_in;  // positions
+    float2* pos_out;
+    const float2* vel_in;  // fluid build: velocities (the predicted ones inside a step, dfsph.rs:512)
+    float2* vel_out;
     const float* r_in;
     float* r_out;
     const float* r2_in;  // tile mode: warm-start arrays travel with the particle (they cannot stay slot-bound across tiles)
@@ -589,14 +597,15 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
     }
     if (dst >= n) return;
-    if (a.pv_in) {
-        float4 pv = a.pv_in[i];
+    if (a.vel_in) {
+        float2 p = a.pos_in[i];
+        const float2 v = a.vel_in[i];
         if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
-            pv.x = pv.x + pv.z * a.advect_dt;
-            pv.y = pv.y + pv.w * a.advect_dt;
+            p.x = p.x + v.x * a.advect_dt;
+            p.y = p.y + v.y * a.advect_dt;
         }
-        a.pv_out[dst] = pv;
-        a.pos_out[dst] = make_float2(pv.x, pv.y);
+        a.pos_out[dst] = p;
+        a.vel_out[dst] = v;
     } else {
         a.pos_out[dst] = a.pos_in[i];
     }
@@ -622,30 +631,16 @@ __global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ a, uint32_
     const uint32_t i = from + blockIdx.x * 256 + threadIdx.x;
     if (i < n) a[i] = v;
 }
-// upload: PV[i] = {pos, vel}
-__global__ __launch_bounds__(256) void k_pack_pv(const float2* __restrict__ pos, const float2* __restrict__ vel, uint32_t n, float4* __restrict__ PV) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float2 p = pos[i], v = vel[i];
-    PV[i] = make_float4(p.x, p.y, v.x, v.y);
-}
-// download: velocities out of PV
-__global__ __launch_bounds__(256) void k_unpack_vel(const float4* __restrict__ PV, uint32_t n, float2* __restrict__ vel) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 pv = PV[i];
-    vel[i] = make_float2(pv.z, pv.w);
-}
 // ---- multi-GPU tiles -------------------------------------------------------------------------------------------------
 // plain advect (dfsph.rs:499-510) for the tile path, where the halo exchange sits between the advection and the re-grid
-__global__ __launch_bounds__(256) void k_advect(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t n, float dt) {
+__global__ __launch_bounds__(256) void k_advect(float2* __restrict__ posA, const float2* __restrict__ vel, uint32_t n, float dt) {
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
-    float4 pv = PV[i];
-    pv.x = pv.x + pv.z * dt;
-    pv.y = pv.y + pv.w * dt;
-    PV[i] = pv;
-    posA[i] = make_float2(pv.x, pv.y);
+    float2 p = posA[i];
+    const float2 v = vel[i];
+    p.x = p.x + v.x * dt;
+    p.y = p.y + v.y * dt;
+    posA[i] = p;
 }
 // 32-byte halo record
 struct HaloRec {
@@ -683,11 +678,11 @@ __device__ __forceinline__ float4 tile_advected(float4 pv, float dt) {
     }
     return pv;
 }
-__global__ __launch_bounds__(256) void k_tile_count(const float4* __restrict__ PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
+__global__ __launch_bounds__(256) void k_tile_count(PVr PV, const uint32_t* __restrict__ pid, uint32_t n, Consts K,
                                                      uint32_t halo, TilePeers P, uint32_t* __restrict__ blk, float dt) {
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t m = i < n ? tile_send_mask(K, P, halo, tile_advected(PV[i], dt), pid[i]) : 0u;
+    const uint32_t m = i < n ? tile_send_mask(K, P, halo, tile_advected(ldpv(PV, i), dt), pid[i]) : 0u;
     for (uint32_t k = 0; k < P.n; ++k) {
         const uint32_t c = (uint32_t)__popcll(__ballot((m >> k) & 1u));
         if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6][k] = c;
@@ -731,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ bl
 // Records out; then: ghosts of the previous step vanish at the next re-grid (a NaN position gets no cell), and so do owned
 // particles that left the tile AND its ghost band.  An owned particle that crossed a cut but is still inside the ghost band
 // stays as a ghost: the new owner receives the very same record in this exchange but cannot send it back before the next one.
-__global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, float2* __restrict__ posA, uint32_t* __restrict__ pid,
+__global__ __launch_bounds__(256) void k_tile_pack(const float2* __restrict__ vel, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
                                                     uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt, CountArgs ca,
                                                     DevScalars* __restrict__ scal, uint32_t write_back) {
@@ -741,15 +736,12 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
     float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t id = 0, m = 0;
     if (i < n) {
-        pv = tile_advected(PV[i], dt);
+        pv = tile_advected(ldpv(PVr{posA, vel}, i), dt);
         id = pid[i];
         m = tile_send_mask(K, P, halo, pv, id);
         // fused advection: the record moves on — unless the re-grid's gather is going to apply the same two operations while it moves
         // the record anyway (write_back = 0: 24 bytes per particle less in this pass)
-        if (dt > 0.0f && write_back) {
-            PV[i] = pv;
-            posA[i] = make_float2(pv.x, pv.y);
-        }
+        if (dt > 0.0f && write_back) posA[i] = make_float2(pv.x, pv.y);
     }
     unsigned long long bal[MAX_TILE_PEERS];
 #pragma unroll
@@ -787,7 +779,6 @@ __global__ __launch_bounds__(256) void k_tile_pack(float4* __restrict__ PV, floa
             pid[i] = id & 0x7FFFFFFFu;
         } else {
             const float nan = __uint_as_float(0x7FC00000u);
-            PV[i].x = nan;
             posA[i].x = nan;
             pkeep.x = nan;
         }
@@ -801,7 +792,7 @@ struct TileInbox {
     uint32_t n;
     const HaloRec* in[MAX_TILE_PEERS];  // nullptr: nothing from that peer
 };
-__global__ __launch_bounds__(256) void k_tile_apply(TileInbox B, uint32_t cap, uint32_t n_base, Consts K, uint32_t halo, float4* __restrict__ PV,
+__global__ __launch_bounds__(256) void k_tile_apply(TileInbox B, uint32_t cap, uint32_t n_base, Consts K, uint32_t halo, float2* __restrict__ vel,
                                                      float2* __restrict__ posA, uint32_t* __restrict__ pid, float* __restrict__ kappa,
                                                      float* __restrict__ stiff, DevScalars* __restrict__ scal) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -816,7 +807,7 @@ __global__ __launch_bounds__(256) void k_tile_apply(TileInbox B, uint32_t cap, u
     const uint32_t dst = n_base + r;
     const float nan = __uint_as_float(0x7FC00000u);
     if (k >= cnt) {
-        PV[dst] = make_float4(nan, 0.0f, 0.0f, 0.0f);
+        vel[dst] = make_float2(0.0f, 0.0f);
         posA[dst] = make_float2(nan, 0.0f);
         pid[dst] = 0;
         return;
@@ -828,7 +819,7 @@ __global__ __launch_bounds__(256) void k_tile_apply(TileInbox B, uint32_t cap, u
     const bool ghost = rect_has(K.tile, cx, cy, halo);
     float4 pv = rec.pv;
     if (!own && !ghost) pv.x = nan;
-    PV[dst] = pv;
+    vel[dst] = make_float2(pv.z, pv.w);
     posA[dst] = make_float2(pv.x, pv.y);
     pid[dst] = rec.id | (own ? 0x80000000u : 0u);
     kappa[dst] = rec.kappa;
@@ -841,15 +832,15 @@ __global__ __launch_bounds__(256) void k_set_ids(uint32_t* __restrict__ pid, con
 
 // boundary tails of the [N|B] arrays: {bpos, 0, 0}
 __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ bpos, uint32_t nb, uint32_t soff, float2* __restrict__ posA,
-                                                     float2* __restrict__ posA2, float4* __restrict__ PV, float4* __restrict__ PV2) {
+                                                     float2* __restrict__ posA2, float2* __restrict__ vel, float2* __restrict__ vel2) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nb) return;
     const float2 p = bpos[j];
-    const float4 r = make_float4(p.x, p.y, 0.0f, 0.0f);
+    const float2 z = make_float2(0.0f, 0.0f);
     posA[soff + j] = p;
     posA2[soff + j] = p;
-    PV[soff + j] = r;
-    PV2[soff + j] = r;
+    vel[soff + j] = z;
+    vel2[soff + j] = z;
 }
 
 // In-kernel stamps (diagnostic builds only, -DSPHX_STAMPS: tools/ab_build.sh): cycles per phase, summed over wavefronts.  The
@@ -988,10 +979,10 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 // MODE 0: lists only; 1: + densities and alpha factors; 2: + the first compute_density_change of the divergence loop that follows
 // (when it starts without a warm start); 3: + that loop's warm start (when it starts with one) — DivArgs.
 struct DivArgs {
-    const float4* PV;   // MODE 2: sorted records, PV.zw = the velocities the divergence loop starts from
+    const float2* vel;  // MODE 2: the velocities the divergence loop starts from, sorted, [N|B]
     float* kbuf;        // MODE 2: receives err * alpha like k_compute_error<true>
     float* warm_zero;   // MODE 2: warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
-    float4* PVw;        // MODE 3: PV.zw of the own particle is corrected in place (nobody reads velocities in this launch)
+    float2* velw;       // MODE 3: the own particle's velocity is corrected in place (nobody reads velocities in this launch)
     const float* warm;  // MODE 3: warm-start stiffness, slot-bound (dfsph.rs:316-344)
     float lim;          // MODE 3: -0.5 rho0^2, dfsph.rs:356-358
 };
@@ -1110,7 +1101,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     if (k0 + u < ct && E[u] >= wlen_b) {
                         const uint32_t gb = w0b + E[u];  // 8 g
                         rj[u] = *(const float2*)((const char*)posA + gb);
-                        if (DIV) vj[u] = *(const float2*)((const char*)dv.PV + (gb * 2u + 8u));  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
+                        if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
                         if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
                     }
             }
@@ -1162,7 +1153,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             dv.warm_zero[i] = 0.0f;
             div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
         }
-        if (WARM) ((float2*)dv.PVw)[2u * i + 1u] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
+        if (WARM) dv.velw[i] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
     }
     // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
     // A list entry names the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
@@ -1295,10 +1286,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     float2 vreg[MODE == 2 ? NWIN : 1];
     float2 vi = make_float2(0.0f, 0.0f);
     if (MODE == 2) {
-        const float2* vel = (const float2*)dv.PV + 1;  // PV[k].zw = vel[2 k]
 #pragma unroll
-        for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = gat(vel, 2u * (w0 + min(threadIdx.x + u * 256u, wlen - 1u)));
-        vi = gat(vel, 2u * (live ? i : b0));
+        for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = gat(dv.vel, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
+        vi = gat(dv.vel, live ? i : b0);
     }
     float sreg[MODE == 3 ? NWIN : 1];
     float warm_i = 0.0f;
@@ -1306,7 +1296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #pragma unroll
         for (uint32_t u = 0; u < NWIN; ++u) sreg[u] = gat(dv.warm, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
         warm_i = gat(dv.warm, live ? i : b0);
-        vi = gat((const float2*)dv.PVw, 2u * (live ? i : b0) + 1u);
+        vi = gat((const float2*)dv.velw, live ? i : b0);
     }
     uint32_t cx, cy;
     cell_of(K, pi, cx, cy);
@@ -1744,7 +1734,7 @@ __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs 
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
+__global__ TRAV_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float rho_s[STAGE_SLOTS];
@@ -1756,7 +1746,7 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
         float rho;
     };
     nb_stage(
-        h, [&](uint32_t g) { return StageRec{gat(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
+        h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
         [&](uint32_t slot, const StageRec& r) {
             rec[slot] = r.pv;
             rho_s[slot] = r.rho;
@@ -1764,7 +1754,7 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
+        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
@@ -1782,7 +1772,7 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
         };
         nb_traverse(
             h, cd, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
-            [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g)}; }, consume);
+            [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
@@ -1790,14 +1780,14 @@ __global__ TRAV_BOUNDS void k_nonpressure(const float4* __restrict__ PV, const f
     block_vmax_add(vsq, scal, vslot);
 }
 
-// a12: dfsph.rs:484-492 — PV.zw becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
+// a12: dfsph.rs:484-492 — vel[] becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
 // va.enabled: this launch is queued right behind the non-pressure pass and READS its max-velocity reduction: every workgroup
 // derives the step the host's TimeManager will arrive at from it (TimerLaw), workgroup 0 publishes vmax and dt.
-__global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const float2* __restrict__ accel, uint32_t n, float dt,
+__global__ __launch_bounds__(256) void k_predict(float2* __restrict__ vel, const float2* __restrict__ accel, uint32_t n, float dt,
                                                   DevScalars* __restrict__ scal, VmaxArgs va, TimerLaw law) {
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     const uint32_t il = min(i, n - 1u);  // (n >= 1: the launch sites skip empty particle sets)
-    float4 pv = PV[il];  // requested before the reduction is read: one round trip, not two
+    float2 v = vel[il];  // requested before the reduction is read: one round trip, not two
     const float2 a = accel[il];
     if (va.enabled) {
         // one wavefront per workgroup reads the stripes and applies the timer law (64-bit divisions: ~150 instructions); the others
@@ -1818,9 +1808,9 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
         dt = dt_s;
     }
     if (i >= n) return;
-    pv.z = pv.z + a.x * dt;
-    pv.w = pv.w + a.y * dt;
-    PV[i] = pv;
+    v.x = v.x + a.x * dt;
+    v.y = v.y + a.y * dt;
+    vel[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1828,18 +1818,19 @@ __global__ __launch_bounds__(256) void k_predict(float4* __restrict__ PV, const 
 // lists and k_density_alpha<Poly6>.
 // ------------------------------------------------------------------------------------------------------------------
 // leap frog 1, wscsph.rs:138-149: v += 0.5*dt*a (v at t+1/2), pos += v*dt
-__global__ __launch_bounds__(256) void k_wcsph_leapfrog1(float4* __restrict__ PV, float2* __restrict__ posA, const float2* __restrict__ accel,
+__global__ __launch_bounds__(256) void k_wcsph_leapfrog1(float2* __restrict__ vel, float2* __restrict__ posA, const float2* __restrict__ accel,
                                                           uint32_t n, float dt) {
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
-    float4 pv = PV[i];
+    const float2 p0 = posA[i], v0 = vel[i];
+    float4 pv = make_float4(p0.x, p0.y, v0.x, v0.y);
     const float2 a = accel[i];
     const float hdt = 0.5f * dt;
     pv.z = pv.z + hdt * a.x;
     pv.w = pv.w + hdt * a.y;
     pv.x = pv.x + pv.z * dt;
     pv.y = pv.y + pv.w * dt;
-    PV[i] = pv;
+    vel[i] = make_float2(pv.z, pv.w);
     posA[i] = make_float2(pv.x, pv.y);
 }
 // f32::powi(x, 7) = compiler-rt __powisf2: square and multiply, in this order
@@ -1855,7 +1846,7 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
     return K.wc_stiffness * (powi7(fmaxf(local_density / K.rho0, 1.0f)) - 1.0f);
 }
 // update_accellerations (wscsph.rs:59-118) + max |v + a*dt|^2 (wscsph.rs:158-161)
-__global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
+__global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                           float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float rho_s[STAGE_SLOTS];
@@ -1867,7 +1858,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
         float rho;
     };
     nb_stage(
-        h, [&](uint32_t g) { return StageRec{gat(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
+        h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
         [&](uint32_t slot, const StageRec& r) {
             rec[slot] = r.pv;
             rho_s[slot] = r.rho;
@@ -1875,7 +1866,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
+        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
         const float rhoi = density[i];
         const uint32_t cd = h.cd, ct = h.ct;
         float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
@@ -1909,7 +1900,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
         };
         nb_traverse(
             h, ct, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
-            [&](uint32_t g) { return Rec{gat(PV, g), gat(density, g < soff ? g : i)}; }, consume);
+            [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g < soff ? g : i)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;
@@ -1922,7 +1913,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(const float4* __restrict__ PV, const f
 // k_i = err_i * alpha_i the correction step needs (dfsph.rs:141,150 / :295,304), and the residual sum (dfsph.rs:221 / :377)
 // ------------------------------------------------------------------------------------------------------------------
 template <bool DIVERGENCE>
-__global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const float* __restrict__ density,
+__global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float* __restrict__ kbuf, float* __restrict__ warm_zero,
                                                         DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la,
@@ -1945,12 +1936,12 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
     // this particle's scalars are requested together with everything else (one round trip, not two)
     const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
     const float alpha_i = i < n ? alpha[i] : 0.0f;
-    nb_stage(h, [&](uint32_t g) { return gat(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
+    nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
         const uint32_t ct = h.ct;
-        const float4 pvi = h.wide ? PV[i] : lds_read_f4(&rec[i - h.lw0]);
+        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
@@ -1961,7 +1952,7 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
                 const float t = delta + (dvx * g.x + dvy * g.y);
                 delta = k < ct ? t : delta;
             };
-            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, [&](uint32_t g) { return gat(PV, g); }, consume);
+            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, [&](uint32_t g) { return ldpv(PV, g); }, consume);
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
@@ -1988,7 +1979,7 @@ __global__ TRAV_BOUNDS void k_compute_error(const float4* __restrict__ PV, const
 // (LoopArgs): then the correction derives the verdict from the residual itself and only the last one counts.
 // hist == nullptr: plain correction.
 template <bool WARM, bool INV_DT>
-__global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float2* __restrict__ posA, const float* __restrict__ kbuf,
+__global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __restrict__ posA, const float* __restrict__ kbuf,
                                                   float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
                                                   const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra) {
@@ -2036,7 +2027,8 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float2* __r
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
-    const float4 pvi = i < n ? PV[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // (position and velocity of the own particle: two 8-byte loads; only the velocity is written back)
+    const float4 pvi = i < n ? ldpv(PVr{posA, vel}, i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float warm_i = i < n ? warm[i] : 0.0f;
     struct StageRec {
         float2 p;
@@ -2127,7 +2119,7 @@ __global__ TRAV_BOUNDS void k_correct(float4* __restrict__ PV, const float2* __r
             o.x = pvi.z - dx * K.mass;  // dfsph.rs:312 / :342
             o.y = pvi.w - dy * K.mass;
         }
-        PV[i] = make_float4(pvi.x, pvi.y, o.x, o.y);
+        vel[i] = o;
         if (!WARM) warm[i] = warm_i + ki;  // dfsph.rs:142 / :296
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
@@ -2177,11 +2169,11 @@ __global__ __launch_bounds__(256) void k_keys_of(const float2* __restrict__ pos,
 __global__ void k_clear_flags(DevScalars* scal, uint32_t mask) { atomicAnd(&scal->flags, ~mask); }
 // viewer feed (main.rs:239-258 draws every particle at its position, coloured by |v|): every stride-th
 // particle as {x, y, |v|}
-__global__ __launch_bounds__(256) void k_view_pack(const float4* __restrict__ PV, uint32_t n, uint32_t stride, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_view_pack(PVr PV, uint32_t n, uint32_t stride, float* __restrict__ out) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint64_t i = (uint64_t)k * stride;
     if (i >= n) return;
-    const float4 pv = PV[i];
+    const float4 pv = ldpv(PV, (uint32_t)i);
     out[3 * (size_t)k + 0] = pv.x;
     out[3 * (size_t)k + 1] = pv.y;
     out[3 * (size_t)k + 2] = sqrtf(pv.z * pv.z + pv.w * pv.w);  // cgmath magnitude()
