@@ -30,12 +30,12 @@ HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): th
 
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
-    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 16-bit
-    list format of this build — every list-consuming traversal moves the count word (4), 2*kbar of entries and 4*rbar of out-of-window
-    table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
+    """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 10-bit
+    list format of this build — every list-consuming traversal moves the count word (4), 4/3*kbar of entries (six to an 8-byte word)
+    and 4*rbar of out-of-window table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
     folded: list traversals per step that the neighbour build does while it still holds the list in registers (the divergence loop's
     first compute_density_change, or its warm start: SPHX_FUSE_DIV) — their list read does not happen and is not counted."""
-    lst = (4 + 2 * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
+    lst = (4 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     if compressed:
         save = (8 + 4 * kbar) - lst  # per traversal
         return (252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--scalar-comm", default="shm", choices=["shm", "torch"],
                     help="per-step scalar all-reduces: shared-memory (one node) or torch.distributed")
     ap.add_argument("--force-tiles", action="store_true", help="drive a single GPU through the tile driver (profiling the multi-GPU code path)")
-    ap.add_argument("--lists-32bit", action="store_true", help="disable the 16-bit neighbour-list compression (A/B runs)")
+    ap.add_argument("--lists-32bit", action="store_true", help="disable the 10-bit neighbour-list compression (A/B runs)")
     ap.add_argument("--solver", default="dfsph", choices=["dfsph", "wcsph"],
                     help="wcsph: the second Solver of the reference (solver/wscsph.rs, cfl factor 0.2, main.rs:116-119) on one GPU")
     ap.add_argument("--no-device-dt", action="store_true", help="plain sphx_step_begin: the device waits for the host's dt (A/B runs)")
@@ -424,7 +424,7 @@ def main():
         bstep_ref = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"])
         bstep = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], compressed=not args.lists_32bit, rbar=rb, folded=folded)
         return {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
-                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 16-bit slots (32-bit fallback per wavefront)",
+                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, six to an 8-byte word (32-bit fallback per wavefront)",
                 "mean_neighbors": kb, "out_of_window_entries_per_particle": rb,
                 "k_and_r": "measured: list entries of the latest neighbour build / particles it ran over" if measured_k else "not measured",
                 "list_traversals_folded_into_the_neighbour_build_per_step": folded,

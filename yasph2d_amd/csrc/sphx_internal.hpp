@@ -41,6 +41,9 @@ constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions 
 constexpr uint32_t LIST_HALO = SPHX_LIST_HALO;
 constexpr uint32_t LIST_WIN = 256 + 2 * LIST_HALO;
 constexpr uint32_t REMOTE_CAP = 512;
+// a narrow list entry = a slot of the staging area (window + out-of-window table = 1024 slots): ten bits, three to a 32-bit word,
+// six to the 8-byte word a lane owns in one row of its wavefront's slice
+constexpr uint32_t ENTRY_BITS = 10, ENTRY_MASK = (1u << ENTRY_BITS) - 1u, GROUP = 6;
 constexpr uint32_t WAVE_REMOTE = REMOTE_CAP / 4;  // every wavefront of a workgroup owns a quarter of the table (its format is decided per wavefront)
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines
 
@@ -73,7 +76,7 @@ struct Consts {
     // spatial tile owned by this context (multi-GPU): the cell rectangle [x0,x1) x [y0,y1); reductions only count owned
     // particles.  Single-GPU default: the whole domain.
     TileRect tile;
-    // a workgroup with at most remote_cap out-of-window neighbour entries stores workgroup-local 16-bit lists (<= REMOTE_CAP;
+    // a workgroup with at most remote_cap out-of-window neighbour entries stores workgroup-local 10-bit lists (<= REMOTE_CAP;
     // 0 forces 32-bit global lists)
     uint32_t remote_cap;
 };

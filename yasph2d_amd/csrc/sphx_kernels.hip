@@ -120,6 +120,8 @@ __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_
 __device__ __forceinline__ uint32_t nb_count_word(uint32_t cd, uint32_t ct, uint32_t r, bool wide) {
     return cd | (ct << 7) | (r << 14) | ((wide ? 1u : 0u) << 31);
 }
+// three 10-bit list entries in one word
+__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return (a & ENTRY_MASK) | ((b & ENTRY_MASK) << ENTRY_BITS) | ((c & ENTRY_MASK) << (2u * ENTRY_BITS)); }
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
@@ -1181,14 +1183,14 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     // of the table (rare) rewrites its rows as 32-bit ones afterwards
     uint32_t run = 0;
     if (cap) {
-        // four rows per trip = one 8-byte word per lane (rows >= m of the last group hold don't-care values: traversals stop at the count)
+        // six rows per trip = one 8-byte word per lane (rows >= m of the last group hold don't-care values: traversals stop at the count)
         const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
         const uint32_t lane8 = lane * 8u;
         const uint32_t* const trow = &tile[w][0][lane];
-        for (uint32_t k0 = 0; k0 < m; k0 += 4u) {
-            uint32_t sl[4];
+        for (uint32_t k0 = 0; k0 < m; k0 += GROUP) {
+            uint32_t sl[GROUP];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < GROUP; ++u) {
                 const uint32_t gl = (uint32_t)((int32_t)lds_read_u32(trow + (k0 + u) * 64u) >> 3) + wshift;  // g - lw0
                 const bool rem = k0 + u < ct && gl >= lwlen;
                 const unsigned long long mask = __ballot(rem);
@@ -1197,9 +1199,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 if (rem && r < WAVE_REMOTE) rtab[r] = gl + lw0;
                 sl[u] = rem ? rbase + r : gl;
             }
-            // the low halves of two registers in one instruction each
-            const uint32_t p0 = __builtin_amdgcn_perm(sl[1], sl[0], 0x05040100u), p1 = __builtin_amdgcn_perm(sl[3], sl[2], 0x05040100u);
-            *(uint2*)(slice + ((k0 >> 2) * 512u + lane8)) = make_uint2(p0, p1);
+            *(uint2*)(slice + ((k0 / GROUP) * 512u + lane8)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
         }
     }
     uint32_t spill_rem = 0, spill_before = 0;
@@ -1217,16 +1217,30 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         const size_t row0 = (size_t)(i >> 6) * 64;
         for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = entry_slot(lds_read_u32(&tile[w][k][lane]), w0);
     } else if (spill) {
-        // entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address, byte
-        // 256 k + 4 lane); their 16-bit home, byte 128 (k & ~3) + 8 lane + 2 (k & 3), lies below every 32-bit row >= k, so
-        // rewriting in ascending k never overwrites an entry still to be read
+        // Entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address: row k at byte
+        // 256 k + 4 lane of the slice).  Their narrow home — the 8-byte word of group q = k / 6 at byte 512 q + 8 lane — lies below
+        // every wide row >= 6 q (q >= 2 here), and the whole wavefront reads the six wide rows of a group before it writes the group's
+        // word: rewriting in ascending q never overwrites an entry still to be read.
         uint32_t r = run + spill_before;
-        for (uint32_t k = STAGE_ROWS; k < ct; ++k) {
-            const uint32_t g = list[ell_index(i, k)];
-            const bool rem = g - lw0 >= lwlen;
-            if (rem) rtab[r] = g;
-            *(uint16_t*)(slice + (k >> 2) * 512u + lane * 8u + (k & 3u) * 2u) = (uint16_t)(rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0);
-            r += rem ? 1u : 0u;
+        uint32_t ctmax = ct;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ctmax = max(ctmax, (uint32_t)__shfl_xor((int)ctmax, d, 64));
+        for (uint32_t k0 = STAGE_ROWS; k0 < ctmax; k0 += GROUP) {
+            uint32_t sl[GROUP];
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; ++u) {
+                const bool on = k0 + u < ct;
+                const uint32_t g = on ? list[ell_index(i, k0 + u)] : lw0;
+                const bool rem = on && g - lw0 >= lwlen;
+                if (rem) rtab[r] = g;
+                sl[u] = rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0;
+                r += rem ? 1u : 0u;
+            }
+            // (all lanes of the wavefront have read this group's wide rows by now: the loads above are complete before the store issues
+            // only per lane, so make it so for the wavefront)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (k0 < ct) *(uint2*)(slice + ((k0 / GROUP) * 512u + lane * 8u)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
         }
     }
     // total number of list entries and of out-of-window entries (stats only): one pair of striped atomics per wavefront
@@ -1415,8 +1429,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
 constexpr uint32_t next_pow2(uint32_t v) { return v <= 1u ? 1u : 2u * next_pow2((v + 1u) / 2u); }
 constexpr uint32_t STAGE_SLOTS = next_pow2(LIST_WIN + REMOTE_CAP);  // LDS staging area (power of two: don't-care list entries are masked into it)
-static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % 4 == 0 && LIST_WIN + REMOTE_CAP <= 65536, "staging loops / packed groups / 16-bit slots");
-constexpr uint32_t NB_G0 = 3;  // packed 4-entry groups every traversal loads up front (12 entries; the rest on demand)
+// A narrow list entry is a slot of that staging area: TEN bits (the window and the out-of-window table together have 1024 slots).
+// Three entries to a 32-bit word, six to the 8-byte word a lane owns in a row of its wavefront's slice: 1.33 bytes per entry
+// (round 2: 16-bit entries, four to the word).
+static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % GROUP == 0 && LIST_WIN + REMOTE_CAP <= (1u << ENTRY_BITS) && STAGE_SLOTS == (1u << ENTRY_BITS),
+              "staging loops / packed groups / 10-bit slots");
+constexpr uint32_t NB_G0 = STAGE_ROWS / GROUP;  // packed 6-entry groups every traversal loads up front (12 entries; the rest on demand)
+
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u32x4_t lds_cu128;
@@ -1433,7 +1452,7 @@ struct NbHead {
     uint32_t cd, ct;      // NeighborRange: dynamic / total neighbours
     uint32_t R;           // entries of this wavefront's quarter of the out-of-window table (0 when wide)
     bool wide;            // this wavefront's lists hold 32-bit global slots (wave-uniform)
-    uint2 e[NB_G0];       // entries 0..11, four 16-bit staging slots per word pair (narrow format)
+    uint2 e[NB_G0];       // entries 0..11, six 10-bit staging slots per word pair (narrow format)
     const char* rows;     // this wave's 16 KiB slice of the list buffer
     uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
@@ -1496,27 +1515,28 @@ __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
 template <class GL, class GG, class C>
 __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& gather_lds, GG&& gather_global, C&& consume) {
     if (!h.wide) {
-        // entries come four to a word pair, but are consumed two at a time: a wavefront whose longest list has 9 or 10 entries does
-        // 10 entry slots of arithmetic, not 12 (the kernels are bound by vector instructions as much as by bytes)
-        auto pair = [&](uint32_t w2, uint32_t k) {
-            const uint32_t s2[2] = {w2 & 0xffffu, w2 >> 16};
-            decltype(gather_lds(0u)) r[2];
+        // entries come six to a word pair; the three of a 32-bit word are read from the staging area together, the third is only
+        // consumed when some lane of the wavefront has it: a wavefront whose longest list has 8 entries does 8 entry slots of
+        // arithmetic, one with 9 does 9 (the kernels are bound by vector instructions as much as by bytes at cache-resident sizes)
+        auto triple = [&](uint32_t w3, uint32_t k) {
+            decltype(gather_lds(0u)) r[3];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) r[u] = gather_lds(s2[u] & (STAGE_SLOTS - 1u));  // entries >= lim hold don't-care values
-#pragma unroll
-            for (int u = 0; u < 2; ++u) consume(r[u], k + (uint32_t)u);
+            for (int u = 0; u < 3; ++u) r[u] = gather_lds((w3 >> (ENTRY_BITS * u)) & ENTRY_MASK);  // entries >= lim hold don't-care values
+            consume(r[0], k);
+            consume(r[1], k + 1u);
+            if (__any(lim > k + 2u)) consume(r[2], k + 2u);
         };
 #pragma unroll
         for (uint32_t q = 0; q < NB_G0; ++q) {
-            if (!__any(lim > 4u * q)) return;
-            pair(h.e[q].x, 4u * q);
-            if (!__any(lim > 4u * q + 2u)) return;
-            pair(h.e[q].y, 4u * q + 2u);
+            if (!__any(lim > GROUP * q)) return;
+            triple(h.e[q].x, GROUP * q);
+            if (!__any(lim > GROUP * q + 3u)) return;
+            triple(h.e[q].y, GROUP * q + 3u);
         }
-        for (uint32_t q = NB_G0; __any(lim > 4u * q); ++q) {
+        for (uint32_t q = NB_G0; __any(lim > GROUP * q); ++q) {
             const uint2 e = *(const uint2*)(h.rows + q * 512u + h.lane * 8u);
-            pair(e.x, 4u * q);
-            if (__any(lim > 4u * q + 2u)) pair(e.y, 4u * q + 2u);
+            triple(e.x, GROUP * q);
+            if (__any(lim > GROUP * q + 3u)) triple(e.y, GROUP * q + 3u);
         }
     } else {
         // round-1 path: 32-bit rows, records gathered from global memory, batches of NB_BATCH with the index loads of the next
@@ -2151,7 +2171,8 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
         if (h.wide) {
             g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
         } else {
-            const uint32_t slot = *(const uint16_t*)(h.rows + (k >> 2) * 512u + h.lane * 8u + (k & 3u) * 2u);
+            const uint32_t word = *(const uint32_t*)(h.rows + (k / GROUP) * 512u + h.lane * 8u + ((k % GROUP) / 3u) * 4u);
+            const uint32_t slot = (word >> (ENTRY_BITS * (k % 3u))) & ENTRY_MASK;
             g = slot < LIST_WIN ? h.lw0 + slot : nb.remote[(size_t)(i >> 8) * REMOTE_CAP + (slot - LIST_WIN)];
         }
         out[s + k] = g < soff ? g : g - soff;
