@@ -983,7 +983,6 @@ __device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot
 struct DivArgs {
     const float2* vel;  // MODE 2: the velocities the divergence loop starts from, sorted, [N|B]
     float* kbuf;        // MODE 2: receives err * alpha like k_compute_error<true>
-    float* warm_zero;   // MODE 2: warm-start stiffness, zeroed like the loop's first iteration does (dfsph.rs:361-363)
     float2* velw;       // MODE 3: the own particle's velocity is corrected in place (nobody reads velocities in this launch)
     const float* warm;  // MODE 3: warm-start stiffness, slot-bound (dfsph.rs:316-344)
     float lim;          // MODE 3: -0.5 rho0^2, dfsph.rs:356-358
@@ -1151,8 +1150,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         alpha[i] = alpha_i;
         if (DIV) {
             const float e = ct < 9u ? 0.0f : fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:261, :277-278
-            dv.kbuf[i] = e * alpha_i;
-            dv.warm_zero[i] = 0.0f;
+            dv.kbuf[i] = e * alpha_i;  // (the warm-start stiffness is not zeroed here: the loop's first correction starts it from zero)
             div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
         }
         if (WARM) dv.velw[i] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
@@ -1981,7 +1979,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
             }
         }
         kbuf[i] = e * alpha_i;  // k = err * alpha: all the correction needs of a neighbour besides its position
-        if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363, folded into the first iteration
+        if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363 (callers whose first correction does not start from zero itself)
         e_owned = tile_owns(K, pvi.x, pvi.y) ? e : 0.0f;
     }
     block_residual_add(e_owned, scal);  // read by the correction queued behind this launch (ResArgs)
@@ -2002,7 +2000,8 @@ template <bool WARM, bool INV_DT>
 __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __restrict__ posA, const float* __restrict__ kbuf,
                                                   float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
-                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra) {
+                                                  const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra,
+                                                  uint32_t first) {
     float dt = WARM ? ca.dt : (la.enabled ? la.dt : ca.dt);
     if (dt_dev) {
         dt = *dt_dev;
@@ -2049,7 +2048,9 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     const NbHead h = nb_head(nb, blk, i, n);
     // (position and velocity of the own particle: two 8-byte loads; only the velocity is written back)
     const float4 pvi = i < n ? ldpv(PVr{posA, vel}, i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float warm_i = i < n ? warm[i] : 0.0f;
+    // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
+    // nothing is read, and nobody had to write that zero either
+    const float warm_i = (i < n && !first) ? warm[i] : 0.0f;
     struct StageRec {
         float2 p;
         float w;
