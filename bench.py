@@ -31,11 +31,11 @@ HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): th
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
     """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 10-bit
-    list format of this build — every list-consuming traversal moves the count word (4), 4/3*kbar of entries (six to an 8-byte word)
+    list format of this build — every list-consuming traversal moves the 16-bit count word (+ one format word per wavefront), 4/3*kbar of entries (six to an 8-byte word)
     and 4*rbar of out-of-window table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
     folded: list traversals per step that the neighbour build does while it still holds the list in registers (the divergence loop's
     first compute_density_change, or its warm start: SPHX_FUSE_DIV) — their list read does not happen and is not counted."""
-    lst = (4 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
+    lst = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     if compressed:
         save = (8 + 4 * kbar) - lst  # per traversal
         return (252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)

@@ -81,17 +81,19 @@ struct Consts {
     uint32_t remote_cap;
 };
 
-// wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 | entries of the
-// workgroup's out-of-window table remote[(i >> 8) * REMOTE_CAP ..] << 14 | wide << 31
+// wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 = NeighborRange
+// (neighborhood_search.rs:269-273) in 16 bits; wave[i >> 6] = entries of the wavefront's quarter of the out-of-window table
+// remote[(i >> 8) * REMOTE_CAP + ((i >> 6) & 3) * WAVE_REMOTE ..] | wide << 31 (the list format is decided per wavefront)
+struct NbView {
+    const uint32_t* list;
+    const uint16_t* counts;
+    const uint32_t* wave;
+    const uint32_t* remote;
+};
 // positions + velocities of the [N|B] arrays as one read view (sphx_kernels.hip: ldpv)
 struct PVr {
     const float2* pos;
     const float2* vel;
-};
-struct NbView {
-    const uint32_t* list;
-    const uint32_t* counts;
-    const uint32_t* remote;
 };
 
 // Two-level Morton cell grid.  dir[] is a small host-built 2D directory over the 64x64-cell blocks of the
@@ -256,7 +258,8 @@ struct sphx_ctx {
     std::vector<float> h_boundary;  // host copy of the boundary (caller order): the static directory is built on the host
     // neighbour lists: wave-sliced ELL, fixed stride: entry k of particle i at ((i>>6)*64 + k)*64 + (i&63)
     uint32_t* nb_list = nullptr;
-    uint32_t* nb_counts = nullptr;  // NeighborRange + list format of the particle's workgroup (nb_count_word)
+    uint16_t* nb_counts = nullptr;  // NeighborRange of every particle (count_dynamic | count_total << 7)
+    uint32_t* nb_wave = nullptr;    // per wavefront (64 particles): out-of-window table lines in use | wide << 31
     uint32_t* nb_remote = nullptr;  // per 256-particle workgroup REMOTE_CAP global record indices
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
@@ -302,7 +305,7 @@ struct sphx_ctx {
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;
-    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_remote}; }
+    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;

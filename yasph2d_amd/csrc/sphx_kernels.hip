@@ -115,11 +115,6 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
 __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
-// NeighborRange (neighborhood_search.rs:269-273) of one particle + the list format of its workgroup in one word:
-// count_dynamic (7 bits) | count_total << 7 | entries of the workgroup's out-of-window table << 14 | wide << 31
-__device__ __forceinline__ uint32_t nb_count_word(uint32_t cd, uint32_t ct, uint32_t r, bool wide) {
-    return cd | (ct << 7) | (r << 14) | ((wide ? 1u : 0u) << 31);
-}
 // three 10-bit list entries in one word
 __device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return (a & ENTRY_MASK) | ((b & ENTRY_MASK) << ENTRY_BITS) | ((c & ENTRY_MASK) << (2u * ENTRY_BITS)); }
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
@@ -1008,7 +1003,7 @@ __device__ __forceinline__ uint32_t entry_slot(uint32_t E, uint32_t w0) { return
 
 template <int MODE>
 __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const GridView& gs,
-                                        uint32_t* __restrict__ list, uint32_t* __restrict__ counts, uint32_t* __restrict__ remote,
+                                        uint32_t* __restrict__ list, uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote,
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
                                         uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
@@ -1209,7 +1204,8 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     }
     const uint32_t rtot = run + spill_rem;
     const bool wide = cap == 0u || rtot > cap;
-    if (live) counts[i] = nb_count_word(cd, ct, wide ? 0u : rtot, wide);
+    if (live) counts[i] = (uint16_t)(cd | (ct << 7));  // NeighborRange, neighborhood_search.rs:269-273
+    if (lane == 0) wave[i >> 6] = (wide ? 0x80000000u : rtot);  // the wavefront's list format + table lines in use
     if (wide) {
         // entries past the staged rows already sit at their 32-bit address
         const size_t row0 = (size_t)(i >> 6) * 64;
@@ -1264,7 +1260,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8, MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8))) void k_neighbor_build(
     const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd, GridView gs, uint32_t* __restrict__ list,
-    uint32_t* __restrict__ counts, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
+    uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
@@ -1405,7 +1401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
     SPHX_STAMP(7)
 }
 
@@ -1463,9 +1459,11 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     const uint32_t c = i < n ? nb.counts[i] : 0u;
     h.cd = c & 0x7fu;
     h.ct = (c >> 7) & 0x7fu;
-    // format and table size are wave-uniform: taken from the wave's first lane (a wave wholly past n: no entries, nothing staged)
-    h.wide = __builtin_amdgcn_readfirstlane(c >> 31) != 0;
-    h.R = h.wide ? 0u : min((uint32_t)__builtin_amdgcn_readfirstlane((c >> 14) & 0x3ffu), WAVE_REMOTE);
+    // format and table size are wave-uniform: one word per wavefront (a wave wholly past n: no entries, nothing staged)
+    const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane(i >> 6);
+    const uint32_t ww = wi * 64u < n ? nb.wave[wi] : 0u;
+    h.wide = (ww >> 31) != 0;
+    h.R = h.wide ? 0u : min(ww & 0x3ffu, WAVE_REMOTE);
     h.lane = i & 63u;
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
 #pragma unroll
@@ -2151,7 +2149,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
 // ------------------------------------------------------------------------------------------------------------------
 // parity helpers (not on the hot path)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_export_counts(const uint32_t* __restrict__ counts, uint32_t n, uint16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void k_export_counts(const uint16_t* __restrict__ counts, uint32_t n, uint16_t* __restrict__ out,
                                                         uint32_t* __restrict__ totals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
