@@ -43,6 +43,29 @@ def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, fo
     return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar) - folded * lst
 
 
+def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=True, fuse_div=True):
+    """Per-particle-step bytes of THIS build's arrays (each per-particle array a pass touches, once; neighbour records
+    assumed cache-served) — smaller than the SURVEY.md §8(d) model above, which prices the reference's array set: positions and
+    velocities are separate 8-byte arrays (a velocity-only pass moves 8 bytes, not 16), the first correction of a loop neither reads
+    nor zeroes the warm-start value, the divergence loop's first compute_density_change (or its warm start) rides on the neighbour
+    build, and a list is 2 + 4/3 k + 4 r bytes."""
+    L = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
+    nonpressure = 16 + 4 + L + 8
+    predict = 24
+    dens_iter_first = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 4 + 8)   # compute_error + correction (+ the re-grid's cell count: 8)
+    dens_iter_more = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 8 + 8)
+    regrid = 6 + 20 + 50                                                  # scan (per particle, dam-break table), scatter, gather
+    build = 8 + 8 + L + 4 + 4 + 4                                         # window of positions + velocities, lists out, density, alpha, k / velocity
+    div_first = (0 if fuse_div else (16 + 4 + L + 4)) + (16 + 12 + L + 8 + 4)
+    div_more = (16 + 4 + L + 4) + (16 + 12 + L + 8 + 8)
+    warm_d = 16 + 8 + 8 + 4 + L
+    warm_v = (4 + 8) if fuse_div else (16 + 8 + 8 + 4 + L)                # on the build: the stiffness window + the velocity write
+    b = nonpressure + predict + regrid + build
+    b += dens_iter_first + max(Id - 1.0, 0.0) * dens_iter_more + Wd * warm_d
+    b += div_first + max(Iv - 1.0, 0.0) * div_more + Wv * warm_v
+    return b
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -423,7 +446,16 @@ def main():
         folded = 1.0 if (fuse_div and args.solver == "dfsph") else 0.0
         bstep_ref = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"])
         bstep = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], compressed=not args.lists_32bit, rbar=rb, folded=folded)
+        blay = bytes_per_particle_step_this_build(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], rb, compressed=not args.lists_32bit,
+                                                   fuse_div=fuse_div and args.solver == "dfsph")
         return {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
+                "bytes_per_particle_step_this_build": blay,
+                "bytes_note": "bytes_per_particle_step = SURVEY.md 8(d)'s list-based model of the reference's array set (what frac_of_hbm_peak_whole_step "
+                              "is computed from, as the survey prescribes); bytes_per_particle_step_this_build = what this build's own arrays add up to "
+                              "(split position/velocity arrays, no warm-start zeroing, folded traversal, 10-bit lists): the HBM rate the device really "
+                              "sustains over the step is achieved_GBs_this_build_per_gpu",
+                "achieved_GBs_this_build_per_gpu": blay * n * steps / elapsed / 1e9,
+                "frac_of_hbm_peak_this_build": blay * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                 "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, six to an 8-byte word (32-bit fallback per wavefront)",
                 "mean_neighbors": kb, "out_of_window_entries_per_particle": rb,
                 "k_and_r": "measured: list entries of the latest neighbour build / particles it ran over" if measured_k else "not measured",
@@ -481,6 +513,13 @@ def main():
         it = iteration_stats(stats)
         kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n
         rbar = float(np.mean([s.get("remote_entries", 0) for s in stats])) / n
+        if roof and roof["kernel"].startswith("neighbor_build+density_alpha+"):
+            # continuity with the round-2 figures: that round priced the fused build at 36 + L (resp. 40 + L) bytes per particle with 16-bit
+            # list entries and a 32-bit count word, L = 2 k + 4 r; this round's lists and arrays are smaller, and so is `achieved`
+            l2 = 2.0 * kbar + 4.0 * rbar + 4.0 / 256
+            b2 = ((36.0 if roof["kernel"].endswith("density_change") else 40.0) + l2) * n
+            roof["round2_byte_definition"] = {"algorithmic_bytes_per_launch": b2, "achieved": b2 / (roof["avg_launch_ms"] * 1e-3) / 1e9,
+                                              "frac": b2 / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         res = dict(scale=scale, n=n, n_boundary=len(boundary), elapsed=elapsed, steps=steps, warmup=warmup, skip_steps=skip_steps, it=it, kbar=kbar, rbar=rbar,
                    roof=roof, value=n * steps / elapsed, ms_per_step=elapsed / steps * 1e3, model=step_model(kbar, rbar, it, n, steps, elapsed, True))
         if solver is not None and hasattr(solver, "close"):
