@@ -116,7 +116,13 @@ __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(l
 __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
 // three 10-bit list entries in one word
-__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return (a & ENTRY_MASK) | ((b & ENTRY_MASK) << ENTRY_BITS) | ((c & ENTRY_MASK) << (2u * ENTRY_BITS)); }
+// (two shifts + two bit-field inserts; whatever c carries above its ten bits lands in bits 30-31, which no reader looks at)
+__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) {
+    constexpr uint32_t M1 = ENTRY_MASK << ENTRY_BITS;
+    uint32_t t = c << (2u * ENTRY_BITS);
+    t = (t & ~M1) | ((b << ENTRY_BITS) & M1);
+    return (t & ~ENTRY_MASK) | (a & ENTRY_MASK);
+}
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
@@ -1176,23 +1182,24 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     // of the table (rare) rewrites its rows as 32-bit ones afterwards
     uint32_t run = 0;
     if (cap) {
-        // six rows per trip = one 8-byte word per lane (rows >= m of the last group hold don't-care values: traversals stop at the count)
+        // three rows per trip = one 32-bit word per lane, half of the 8-byte word the lane owns in a row group (rows >= m of the last
+        // word hold don't-care values: traversals stop at the count)
         const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
         const uint32_t lane8 = lane * 8u;
         const uint32_t* const trow = &tile[w][0][lane];
-        for (uint32_t k0 = 0; k0 < m; k0 += GROUP) {
-            uint32_t sl[GROUP];
+        for (uint32_t k0 = 0; k0 < m; k0 += 3u) {
+            uint32_t sl[3];
 #pragma unroll
-            for (uint32_t u = 0; u < GROUP; ++u) {
+            for (uint32_t u = 0; u < 3; ++u) {
                 const uint32_t gl = (uint32_t)((int32_t)lds_read_u32(trow + (k0 + u) * 64u) >> 3) + wshift;  // g - lw0
                 const bool rem = k0 + u < ct && gl >= lwlen;
-                const unsigned long long mask = __ballot(rem);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(rem);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, run));
                 run += (uint32_t)__popcll(mask);
                 if (rem && r < WAVE_REMOTE) rtab[r] = gl + lw0;
                 sl[u] = rem ? rbase + r : gl;
             }
-            *(uint2*)(slice + ((k0 / GROUP) * 512u + lane8)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
+            *(uint32_t*)(slice + ((k0 / GROUP) * 512u + ((k0 / 3u) & 1u) * 4u + lane8)) = pack3(sl[0], sl[1], sl[2]);
         }
     }
     uint32_t spill_rem = 0, spill_before = 0;
