@@ -22,7 +22,12 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_NEIGHBORS = 64;  // neighborhood_search.rs:322
 constexpr uint32_t BLOCK_SHIFT = 6;     // directory blocks are 64x64 cells
 constexpr uint32_t BLOCK_CELLS = 4096;  // cells per block = low 12 Morton bits
-constexpr uint32_t SCAN_TILE = 4096;    // elements per scan workgroup (256 threads x 16)
+constexpr uint32_t SCAN_TILE = 4096;    // elements per workgroup of the two-launch scan (256 threads x 16)
+#ifndef SPHX_SCAN_ITEMS
+#define SPHX_SCAN_ITEMS 16
+#endif
+constexpr uint32_t SCAN1_ITEMS = SPHX_SCAN_ITEMS;        // one-launch (look-back) scan: table entries per thread (a multiple of 4)
+constexpr uint32_t SCAN1_TILE = 256 * SCAN1_ITEMS;       // ... per workgroup
 #ifndef SPHX_STAGE_ROWS
 #define SPHX_STAGE_ROWS 12
 #endif

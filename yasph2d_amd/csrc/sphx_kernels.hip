@@ -366,15 +366,15 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
                                                        DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total, Mailbox* __restrict__ mb,
                                                        uint32_t mb_seq) {
     const uint32_t bid = blockIdx.x;
-    const uint32_t base = bid * SCAN_TILE;
-    uint32_t v[16];
+    const uint32_t base = bid * SCAN1_TILE;
+    uint32_t v[SCAN1_ITEMS];
     uint32_t s = 0;
-    const uint32_t t0 = base + threadIdx.x * 16;
-    const bool full = t0 + 16 <= len;
+    const uint32_t t0 = base + threadIdx.x * SCAN1_ITEMS;
+    const bool full = t0 + SCAN1_ITEMS <= len;
     if (full) {
         uint4* p4 = reinterpret_cast<uint4*>(in + t0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (uint32_t k = 0; k < SCAN1_ITEMS / 4; ++k) {
             const uint4 q = p4[k];
             v[4 * k] = q.x;
             v[4 * k + 1] = q.y;
@@ -384,13 +384,13 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) {
             v[k] = (t0 + k < len) ? in[t0 + k] : 0;
             if (t0 + k < len) in[t0 + k] = 0;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += v[k];
+    for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) s += v[k];
     uint32_t total;
     uint32_t run = block_excl_scan_256(s, &total);
     __shared__ uint32_t excl_s;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     if (full) {
         uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (uint32_t k = 0; k < SCAN1_ITEMS / 2; ++k) {
             uint4 q;
             q.x = run;
             run += v[2 * k];
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) {
             if (t0 + k < len) out[t0 + k] = make_uint2(run, run + v[k]);
             run += v[k];
         }
