@@ -423,3 +423,39 @@ def test_divergence_error_folded_into_the_neighbour_build_changes_nothing(monkey
         assert_bits_equal(a[k], b[k], k)
     for k in ("kappa", "stiffness", "alpha"):
         assert_bits_equal(sa[k], sb[k], k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tolerance_scale", [1.0, 0.1])
+def test_prediction_folded_into_the_first_density_iteration_changes_nothing(monkeypatch, tolerance_scale):
+    """With the timer law on the device and no density warm start ahead, the first compute_density_error of a step also does the
+    velocity prediction (k_compute_error<false, true>: dt from the max-velocity reduction, neighbours staged as v + a dt, own result
+    into the other velocity buffer).  SPHX_FUSE_PREDICT=0 runs the separate k_predict.  Same bits, time steps and counts — through
+    free fall and the impact; a particle block added mid-run (warm-up block, changed count) included.  With the reference's
+    tolerance the density loop of this scene never needs a second iteration (no density warm start ever: every step is a fused one);
+    with a tenth of it steps with a density warm start occur (around the impact), and the separate k_predict takes over for those."""
+    def run(fused):
+        monkeypatch.setenv("SPHX_FUSE_PREDICT", "1" if fused else "0")
+        w = y.FluidParticleWorld()
+        w.reset_fluid(1.0)
+        t = y.TimeManager()
+        p = y.default_params(fixed_iterations=(0, 0))
+        p.max_avg_density_error *= tolerance_scale
+        s = y.DFSPHSolver(w, p)
+        st = [s.simulation_step(w, t, sync_world=False) for _ in range(300)]
+        s.sync_world(w)
+        w.add_fluid_rect(1.2, 1.0, 0.2, 0.2, 0.05)
+        st += [s.simulation_step(w, t, sync_world=False) for _ in range(60)]
+        s.sync_world(w)
+        return np.array(w.positions), np.array(w.velocities), np.array(w.densities), t.total_simulated_ns, [
+            (x["density_iterations"], x["divergence_iterations"], x["warmstart_density"], np.float32(x["avg_density_error"]).tobytes()) for x in st]
+
+    pa, va, da, ta, ca = run(True)
+    pb, vb, db, tb, cb = run(False)
+    assert ta == tb and ca == cb
+    assert sum(1 for c in ca if not c[2]) > 100, "steps without a density warm start (the fused ones) must occur"
+    if tolerance_scale < 1.0:
+        assert any(c[2] for c in ca), "steps with a density warm start must occur"
+    assert_bits_equal(pa, pb, "pos")
+    assert_bits_equal(va, vb, "vel")
+    assert_bits_equal(da, db, "density")

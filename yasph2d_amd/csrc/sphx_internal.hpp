@@ -121,9 +121,16 @@ struct alignas(128) Stripe {
     // iterations so far (never reset: readers take differences); vmax[]: max |v + a dt|^2 bits, a ring of 4 (the reader of slot v
     // clears slot v + 2).
     unsigned long long res_hi, res_lo;
-    uint32_t vmax[4];
     uint32_t ticket;                // first-level arrival counter of the last-block reduction (two-pass scan only)
-    uint32_t pad[17];
+    uint32_t pad[21];
+};
+// The max-velocity ring lives on cache lines of its own: the first density iteration READS it (velocity prediction folded into
+// compute_density_error) while workgroups of the same launch that have finished ADD their residual to Stripe — with both on one
+// line every one of those atomics sent the readers of that line back to the fabric (19.5 -> 31.7 us per launch at 1M particles
+// once the residuals are non-zero, profiles/r03_experiments/predict_fusion.txt).
+struct alignas(128) VmaxStripe {
+    uint32_t vmax[4];
+    uint32_t pad[28];
 };
 struct DevScalars {
     uint32_t flags;        // DF_*
@@ -135,6 +142,7 @@ struct DevScalars {
     unsigned long long snap_hi[2], snap_lo[2];  // cumulative residual sums after the iteration with reduction sequence number r at [r & 1]
     uint32_t pad[18];
     Stripe stripe[STRIPES];
+    VmaxStripe vstripe[STRIPES];
 };
 
 // Pinned, host-coherent memory the device publishes step scalars into (no D2H copy, no stream sync on the fast path).
@@ -294,6 +302,10 @@ struct sphx_ctx {
     float sub_ahead_dt = 0.0f;  // sphx_sub_run_ahead: the next sphx_sub_iteration queues the next step's non-pressure pass behind its kernels
     bool tile_carry_kappa = true, tile_carry_stiff = true;  // sphx_tile_carry_warmstart: which warm-start arrays the re-grid's gather moves
     int run_ahead = 1;
+#ifndef SPHX_DEFAULT_FUSE_PREDICT
+#define SPHX_DEFAULT_FUSE_PREDICT 1
+#endif
+    int fuse_predict = SPHX_DEFAULT_FUSE_PREDICT;  // SPHX_FUSE_PREDICT=0: the velocity prediction is never folded into the first compute_density_error
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it
     bool div_warm_fused = false;   // the latest neighbour build applied the divergence loop's warm start

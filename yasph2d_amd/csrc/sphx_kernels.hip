@@ -1458,12 +1458,21 @@ struct NbHead {
     uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
     const uint32_t* rtab; // this wavefront's quarter of the workgroup's table
+    uint32_t g[WAVE_REMOTE / 64];  // this lane's lines of it: [N|B] slots (lines past R: don't-care)
 };
 __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
     NbHead h;
     const uint32_t b0 = blk * 256u;
     const bool active = b0 < n;  // the grid is rounded up: workgroups past the last particle have no lists
-    const uint32_t c = i < n ? nb.counts[i] : 0u;
+    // The table lines are requested before anything else: the addresses of the out-of-window records come from them (the only
+    // two-step chain of the staging), and loads return in order — behind the list words they would arrive with the last of those.
+    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
+#pragma unroll
+    for (uint32_t u = 0; u < WAVE_REMOTE / 64; ++u) h.g[u] = active ? h.rtab[(threadIdx.x & 63u) + u * 64u] : 0u;
+    // clamped, not predicated: behind a branch the compiler unpacks the word INSIDE it and waits for the load there — a whole
+    // round trip before the first of the other loads was even requested
+    const uint32_t craw = nb.counts[min(i, n ? n - 1u : 0u)];
+    const uint32_t c = i < n ? craw : 0u;
     h.cd = c & 0x7fu;
     h.ct = (c >> 7) & 0x7fu;
     // format and table size are wave-uniform: one word per wavefront (a wave wholly past n: no entries, nothing staged)
@@ -1477,31 +1486,62 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
     h.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
-    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
     return h;
 }
 // Fill the staging area: load(g) -> record of slot g of the [N|B] arrays (any type), store(slot, record) writes it to LDS.  Every
 // load of a thread is issued before the first store (the loads of the out-of-window lines wait for nothing but the table lines
 // and the count word, which were requested first).  The window is staged by all 256 threads together, a wavefront's quarter of the
 // table by that wavefront (only its own lists point there).  The caller places the barrier.
+constexpr uint32_t NB_NW = (LIST_WIN + 255) / 256, NB_NR = WAVE_REMOTE / 64;
+template <class R>
+struct NbStaged {  // the records a thread has requested for the staging area: window slots and its share of the wavefront's table lines
+    R w[NB_NW], r[NB_NR];
+    uint32_t g[NB_NR];  // [N|B] slots of the table lines
+};
+template <class L>
+__device__ __forceinline__ auto nb_stage_load(const NbHead& h, L&& load) -> NbStaged<decltype(load(0u))> {
+    NbStaged<decltype(load(0u))> st;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t (&g)[NB_NR] = st.g;
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NR; ++u) g[u] = h.g[u];
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NW; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        st.w[u] = load(h.lw0 + min(t, h.lwlen ? h.lwlen - 1u : 0u));  // clamped, not predicated: no branch between the loads
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
+    return st;
+}
+template <class R, class S>
+__device__ __forceinline__ void nb_stage_store(const NbHead& h, const NbStaged<R>& st, S&& store) {
+    const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NW; ++u) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        if (t < h.lwlen) store(t, st.w[u], h.lw0 + t);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NR; ++u)
+        if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, st.r[u], st.g[u]);
+}
 template <class L, class S>
 __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
     if (h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
     constexpr uint32_t NW = (LIST_WIN + 255) / 256, NR = WAVE_REMOTE / 64;
     const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
-    uint32_t g[NR];
-#pragma unroll
-    for (uint32_t u = 0; u < NR; ++u) g[u] = h.rtab[lane + u * 64u];  // lines past R: don't-care
+    const uint32_t (&g)[NR] = h.g;
     decltype(load(0u)) wrec[NW], rrec[NR];
 #pragma unroll
     for (uint32_t u = 0; u < NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;
         wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads
     }
-#pragma unroll
 #ifdef SPHX_ABL_NOREMOTE  // (traffic experiments: the out-of-window records are NOT fetched — results are wrong)
     for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(h.lw0);
 #else
+#pragma unroll
     for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
 #endif
 #pragma unroll
@@ -1658,12 +1698,12 @@ __device__ __forceinline__ unsigned long long timer_law_step_ns(const TimerLaw& 
 // max |v + a dt|^2: non-negative floats order like their bit patterns (NaN patterns sort above +inf: a NaN is not lost)
 __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t m = block_max_u32(__float_as_uint(vsq));
-    if (threadIdx.x == 0 && m) atomicMax(&scal->stripe[blockIdx.x % STRIPES].vmax[vslot & 3u], m);
+    if (threadIdx.x == 0 && m) atomicMax(&scal->vstripe[blockIdx.x % STRIPES].vmax[vslot & 3u], m);
 }
 // called by a whole wavefront; every lane returns the maximum
 __device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t b = lane < STRIPES ? scal->stripe[lane].vmax[vslot & 3u] : 0u;  // plain load, as in residual_stripe_load
+    uint32_t b = lane < STRIPES ? scal->vstripe[lane].vmax[vslot & 3u] : 0u;  // plain load, as in residual_stripe_load
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
     return b;
@@ -1671,7 +1711,7 @@ __device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__
 // The reader's workgroup 0 (its first wavefront) clears the slot that comes into use two reductions later and publishes.
 __device__ __forceinline__ void vmax_publish(DevScalars* __restrict__ scal, const VmaxArgs& va, uint32_t bits, const TimerLaw& law, unsigned long long ns,
                                              float dt_new) {
-    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->stripe[threadIdx.x].vmax[(va.vslot + 2u) & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->vstripe[threadIdx.x].vmax[(va.vslot + 2u) & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) {
         va.mb->vmax_sq_bits = bits;
         if (law.enabled) {
@@ -1745,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_block_occupancy(const uint2* __restrict
 // A non-pressure pass that ran ahead of its step and was discarded (sphx_ctx::ahead) has left its maximum in a slot: cleared before
 // the pass runs again into the same slot, so that every step still consumes exactly one slot of the ring.
 __global__ __launch_bounds__(64) void k_clear_vmax_slot(DevScalars* scal, uint32_t vslot) {
-    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->stripe[threadIdx.x].vmax[vslot & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < STRIPES) __hip_atomic_store(&scal->vstripe[threadIdx.x].vmax[vslot & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Reader of the max-velocity reduction when no kernel of the step is queued behind it (plain sphx_step_begin, WCSPH, tiles)
@@ -1935,12 +1975,24 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
 // a14 / a19: compute_density_error (dfsph.rs:99-126) / compute_density_change (dfsph.rs:249-280), the per-particle stiffness
 // k_i = err_i * alpha_i the correction step needs (dfsph.rs:141,150 / :295,304), and the residual sum (dfsph.rs:221 / :377)
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DIVERGENCE>
+// PREDICT (first density iteration of a step that starts without a warm start): the launch also IS the velocity prediction of
+// dfsph.rs:484-492.  Every workgroup derives dt from the max-velocity reduction the non-pressure pass left (the timer law, as
+// k_predict does), stages its neighbours' records as {x, v + a dt} — the same two operations the prediction would have applied to
+// them — and writes its own particles' predicted velocities to pa.vel_out (the OTHER velocity buffer: neighbouring workgroups are
+// staging the old ones meanwhile; the host swaps the two pointers behind the launch).  One launch and the prediction's 24 bytes per
+// particle less, for 8 more staged bytes and an 8-byte store here.
+struct PredArgs {
+    const float2* accel;  // [N]; boundary records: a = 0
+    float2* vel_out;
+    VmaxArgs va;
+    TimerLaw law;
+};
+template <bool DIVERGENCE, bool PREDICT = false>
 __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ density,
                                                         const float* __restrict__ alpha, uint32_t n, uint32_t soff, Consts K, float dt,
                                                         NbView nb, float* __restrict__ kbuf, float* __restrict__ warm_zero,
                                                         DevScalars* __restrict__ scal, const float* __restrict__ dt_dev, LoopArgs la,
-                                                        uint32_t* __restrict__ clear_hist, uint32_t clear_len) {
+                                                        uint32_t* __restrict__ clear_hist, uint32_t clear_len, PredArgs pa) {
     // device-run loop: an iteration queued behind the one that met the residual test has nothing to do
     if (la.enabled && la.iter > 1u && scal->loop_done != 0u) return;
     if (dt_dev) dt = *dt_dev;
@@ -1959,12 +2011,42 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     // this particle's scalars are requested together with everything else (one round trip, not two)
     const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
     const float alpha_i = i < n ? alpha[i] : 0.0f;
-    nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
+    struct PredRec {
+        float4 pv;
+        float2 a;
+    };
+    auto load_pred = [&](uint32_t g) { return PredRec{ldpv(PV, g), gat(pa.accel, g < soff ? g : 0u)}; };  // accel[] has no boundary tail
+    auto predicted = [&](const PredRec& r, uint32_t g) {  // dfsph.rs:484-492, the operations of k_predict; boundary records keep v = 0
+        return g < soff ? make_float4(r.pv.x, r.pv.y, r.pv.z + r.a.x * dt, r.pv.w + r.a.y * dt) : r.pv;
+    };
+    if (PREDICT) {
+        // The reduction's stripes are requested FIRST (loads return in order: behind the staging loads the maximum would arrive last),
+        // then all records; the first wavefront applies the timer law while the records are in flight.
+        uint32_t vb = 0;
+        if (threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
+        const NbStaged<PredRec> st = nb_stage_load(h, load_pred);
+        __shared__ float dt_s;
+        if (threadIdx.x < 64) {
+            uint32_t b = vb;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+            const unsigned long long ns = timer_law_step_ns(pa.law, sqrtf(__uint_as_float(b)));
+            const float d = duration_as_secs_f32(ns);
+            if (threadIdx.x == 0) dt_s = d;
+            if (blockIdx.x == 0) vmax_publish(scal, pa.va, b, pa.law, ns, d);
+        }
+        __syncthreads();
+        dt = dt_s;
+        nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { rec[slot] = predicted(r, g); });
+    } else {
+        nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
+    }
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
         const uint32_t ct = h.ct;
-        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
+        float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
+        if (PREDICT && h.wide) pvi = predicted(load_pred(i), i);
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
@@ -1975,7 +2057,8 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
                 const float t = delta + (dvx * g.x + dvy * g.y);
                 delta = k < ct ? t : delta;
             };
-            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); }, [&](uint32_t g) { return ldpv(PV, g); }, consume);
+            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); },
+                        [&](uint32_t g) { return PREDICT ? predicted(load_pred(g), g) : ldpv(PV, g); }, consume);
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
@@ -1984,6 +2067,9 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
             }
         }
         kbuf[i] = e * alpha_i;  // k = err * alpha: all the correction needs of a neighbour besides its position
+        // the predicted velocity of the own particle (staged with the window).  Stored HERE, behind the walk: a store in front of it
+        // sits in the same counter as the walk's entry loads, and every wait for one of those waited for the store's acknowledge too
+        if (PREDICT) pa.vel_out[i] = make_float2(pvi.z, pvi.w);
         if (warm_zero) warm_zero[i] = 0.0f;  // dfsph.rs:206-208 / 361-363 (callers whose first correction does not start from zero itself)
         e_owned = tile_owns(K, pvi.x, pvi.y) ? e : 0.0f;
     }
