@@ -45,7 +45,7 @@ extern "C" {
 
 #define SPHX_ABI_VERSION 3 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
                             * 3: sphx_comm_ops.abort, sphx_multi_info_t list statistics, sphx_shm_abort (and sphx_shm_open as a collective),
-                            *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect */
+                            *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect, sphx_sub_predict_iteration */
 
 /* ---- status codes ---- */
 enum {
@@ -270,6 +270,9 @@ int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* df
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */
 int sphx_sub_iteration(sphx_ctx* ctx, int divergence, float dt, int first, double* out_err_sum, uint64_t* out_n_owned); /* :217-221 / :372-377 */
 int sphx_sub_advect(sphx_ctx* ctx, float dt);                              /* dfsph.rs:499-510 */
+/* sphx_sub_predict followed by sphx_sub_iteration(divergence = 0, first = 1) in one call, for a density loop that starts without a
+ * warm start (dfsph.rs:199): one list walk does both (the prediction costs no pass of its own).  Same results as the two calls. */
+int sphx_sub_predict_iteration(sphx_ctx* ctx, float dt, double* out_err_sum, uint64_t* out_n_owned);
 
 
 /* ---- multi-GPU solver behind the Solver boundary ("device list ... internally may drive 1-8 GPUs") ----------------

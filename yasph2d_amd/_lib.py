@@ -147,6 +147,7 @@ SIGNATURES = {
     "sphx_sub_predict": (_i, [_vp, _f]),
     "sphx_sub_warmstart": (_i, [_vp, _i, _f]),
     "sphx_sub_iteration": (_i, [_vp, _i, _f, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "sphx_sub_predict_iteration": (_i, [_vp, _f, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "sphx_sub_advect": (_i, [_vp, _f]),
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -306,6 +306,11 @@ struct sphx_ctx {
 #define SPHX_DEFAULT_FUSE_PREDICT 1
 #endif
     int fuse_predict = SPHX_DEFAULT_FUSE_PREDICT;  // SPHX_FUSE_PREDICT=0: the velocity prediction is never folded into the first compute_density_error
+    // tile path: the last density correction classifies its particles for the halo exchange (TileClassArgs; SPHX_TILE_FUSE_CLASS=0: off)
+    int tile_fuse_class = 1;
+    bool tile_class_done = false;   // ... has happened, for tile_class_n particles advected by the dt with these bits
+    uint32_t tile_class_n = 0, tile_class_dt_bits = 0;
+    bool tile_fix_owner = false;    // the re-grid's gather clears the owner bit of kept particles that left the own rectangle
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it
     bool div_warm_fused = false;   // the latest neighbour build applied the divergence loop's warm start

@@ -568,6 +568,11 @@ struct GatherArgs {
     DevScalars* flags;        // DF_DENSE_CELL goes here
     float advect_dt;          // > 0: the fluid build inside a step — positions advance by v*dt while the records move
     uint32_t advect_below;    // ... for the records with a previous index below this (tile path: the arrivals behind them are already advected)
+    // tile path, classification done by the last density correction (TileClassArgs): a record below advect_below whose advected
+    // position has left the tile's own rectangle stays as a ghost — its owner bit goes while it moves (k_tile_pack did that)
+    uint32_t fix_owner;
+    float cell_inv, gmin_x, gmin_y;  // Consts of cell_of()
+    TileRect own;
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
@@ -600,23 +605,25 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
     }
     if (dst >= n) return;
+    float2 q = a.pos_in[i];  // the record's position as it arrives at dst
     if (a.vel_in) {
-        float2 p = a.pos_in[i];
         const float2 v = a.vel_in[i];
         if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
-            p.x = p.x + v.x * a.advect_dt;
-            p.y = p.y + v.y * a.advect_dt;
+            q.x = q.x + v.x * a.advect_dt;
+            q.y = q.y + v.y * a.advect_dt;
         }
-        a.pos_out[dst] = p;
         a.vel_out[dst] = v;
-    } else {
-        a.pos_out[dst] = a.pos_in[i];
     }
+    a.pos_out[dst] = q;
     if (a.r_in) a.r_out[dst] = a.r_in[i];
     if (a.r2_in) a.r2_out[dst] = a.r2_in[i];
     if (a.r3_in) a.r3_out[dst] = a.r3_in[i];
     if (a.u_in) {
-        const uint32_t id = a.u_in[i];
+        uint32_t id = a.u_in[i];
+        if (a.fix_owner && i < a.advect_below) {
+            const uint32_t cx = sat_u16((q.x - a.gmin_x) * a.cell_inv), cy = sat_u16((q.y - a.gmin_y) * a.cell_inv);  // cell_of()
+            if (!rect_has(a.own, cx, cy, 0u)) id &= 0x7FFFFFFFu;
+        }
         a.u_out[dst] = id;
         if (a.count_owned) {
             const unsigned long long m = __ballot((id >> 31) != 0);
@@ -663,15 +670,29 @@ struct TilePeers {
     TileRect rect[MAX_TILE_PEERS];
     HaloRec* out[MAX_TILE_PEERS];  // send buffers: record 0 = header (count), then the records
 };
-__device__ __forceinline__ uint32_t tile_send_mask(const Consts& K, const TilePeers& P, uint32_t halo, float4 pv, uint32_t id) {
+__device__ __forceinline__ uint32_t tile_send_mask(const Consts& K, const TileRect* rect, uint32_t nrect, uint32_t halo, float4 pv, uint32_t id) {
     const bool owned = (id >> 31) != 0 && pv.x == pv.x;
     if (!owned) return 0u;
     uint32_t cx, cy;
     cell_of(K, make_float2(pv.x, pv.y), cx, cy);
     uint32_t m = 0;
-    for (uint32_t k = 0; k < P.n; ++k) m |= rect_has(P.rect[k], cx, cy, halo) ? (1u << k) : 0u;
+    for (uint32_t k = 0; k < nrect; ++k) m |= rect_has(rect[k], cx, cy, halo) ? (1u << k) : 0u;
     return m;
 }
+__device__ __forceinline__ uint32_t tile_send_mask(const Consts& K, const TilePeers& P, uint32_t halo, float4 pv, uint32_t id) {
+    return tile_send_mask(K, P.rect, P.n, halo, pv, id);
+}
+// The last density correction of a step holds the advected position of its particle in registers (it does the re-grid's cell count
+// with it): in a tile it also does what k_tile_count and most of k_tile_pack read every particle again for — the send counts per
+// workgroup and neighbour, and the verdict on what the tile keeps (a retired particle simply gets no cell).  k_tile_pack then only
+// visits the workgroups that send something; the owner bit of a particle that stays as a ghost goes in the re-grid's gather.
+struct TileClassArgs {
+    const uint32_t* pid;  // nullptr: not wanted
+    uint32_t* blk;        // [workgroup][MAX_TILE_PEERS]: send counts (k_tile_offsets turns them into offsets)
+    uint32_t* any;        // [workgroup]: != 0 iff the workgroup sends anything
+    uint32_t halo, n;
+    TileRect rect[MAX_TILE_PEERS];
+};
 // dt > 0: the advection x += v* dt (dfsph.rs:499-510) is applied on the fly — k_tile_pack then also stores the advected record, so
 // the tile step needs no separate advection pass in front of the exchange
 __device__ __forceinline__ float4 tile_advected(float4 pv, float dt) {
@@ -732,7 +753,10 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(uint32_t* __restrict__ bl
 __global__ __launch_bounds__(256) void k_tile_pack(const float2* __restrict__ vel, float2* __restrict__ posA, uint32_t* __restrict__ pid,
                                                     const float* __restrict__ kappa, const float* __restrict__ stiff, uint32_t n, Consts K,
                                                     uint32_t halo, TilePeers P, const uint32_t* __restrict__ blk, uint32_t cap, float dt, CountArgs ca,
-                                                    DevScalars* __restrict__ scal, uint32_t write_back) {
+                                                    DevScalars* __restrict__ scal, uint32_t write_back, const uint32_t* __restrict__ any) {
+    // any != nullptr: the last density correction has classified the particles (TileClassArgs) — only the records are left to do,
+    // and only in the workgroups that send some
+    if (any && any[blockIdx.x] == 0u) return;
     __shared__ uint32_t wc[4][MAX_TILE_PEERS];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -770,6 +794,7 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float2* __restrict__ ve
             }
         }
     }
+    if (any) return;
     float2 pkeep = make_float2(pv.x, pv.y);  // where the particle is if the tile keeps it (NaN x: retired)
     if (i < n) {
         const bool valid = (id >> 31) != 0 && pv.x == pv.x;
@@ -2022,11 +2047,12 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     if (PREDICT) {
         // The reduction's stripes are requested FIRST (loads return in order: behind the staging loads the maximum would arrive last),
         // then all records; the first wavefront applies the timer law while the records are in flight.
+        // (pa.va.enabled == 0 — tile path: dt is the host's, all-reduced over the tiles; no law here)
         uint32_t vb = 0;
-        if (threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
+        if (pa.va.enabled && threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
         const NbStaged<PredRec> st = nb_stage_load(h, load_pred);
         __shared__ float dt_s;
-        if (threadIdx.x < 64) {
+        if (pa.va.enabled && threadIdx.x < 64) {
             uint32_t b = vb;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
@@ -2035,8 +2061,10 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
             if (threadIdx.x == 0) dt_s = d;
             if (blockIdx.x == 0) vmax_publish(scal, pa.va, b, pa.law, ns, d);
         }
-        __syncthreads();
-        dt = dt_s;
+        if (pa.va.enabled) {
+            __syncthreads();
+            dt = dt_s;
+        }
         nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { rec[slot] = predicted(r, g); });
     } else {
         nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
@@ -2092,7 +2120,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
                                                   float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
                                                   const float* __restrict__ dt_dev, CountArgs ca, DevScalars* __restrict__ scal, LoopArgs la, ResArgs ra,
-                                                  uint32_t first) {
+                                                  uint32_t first, TileClassArgs tc) {
     float dt = WARM ? ca.dt : (la.enabled ? la.dt : ca.dt);
     if (dt_dev) {
         dt = *dt_dev;
@@ -2142,6 +2170,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
     // nothing is read, and nobody had to write that zero either
     const float warm_i = (i < n && !first) ? warm[i] : 0.0f;
+    const uint32_t id_i = (!WARM && INV_DT && tc.pid && i < n) ? tc.pid[i] : 0u;
     struct StageRec {
         float2 p;
         float w;
@@ -2236,7 +2265,31 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
     if (!WARM && INV_DT)
-        if (ca.hist) count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);  // every density correction counts
+        if (ca.hist) {
+            if (tc.pid) {  // tile: k_tile_count's and k_tile_pack's verdicts, from the position in registers
+                __shared__ uint32_t wc[4][MAX_TILE_PEERS];
+                const uint32_t m = i < n ? tile_send_mask(K, tc.rect, tc.n, tc.halo, make_float4(pnew.x, pnew.y, 0.0f, 0.0f), id_i) : 0u;
+                for (uint32_t k = 0; k < tc.n; ++k) {
+                    const uint32_t c = (uint32_t)__popcll(__ballot((m >> k) & 1u));
+                    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6][k] = c;
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    const uint32_t v = threadIdx.x < tc.n ? wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x] : 0u;
+                    if (threadIdx.x < MAX_TILE_PEERS) tc.blk[(size_t)blk * MAX_TILE_PEERS + threadIdx.x] = v;
+                    const unsigned long long sends = __ballot(v != 0u);
+                    if (threadIdx.x == 0) tc.any[blk] = sends ? 1u : 0u;
+                }
+                if (i < n) {
+                    // what the tile keeps: its own particles (owner bit) that are still inside the rectangle grown by the ghost band;
+                    // last step's ghosts and whatever left the band get no cell (k_tile_pack marked those with a NaN position)
+                    uint32_t cx, cy;
+                    cell_of(K, pnew, cx, cy);
+                    if (!((id_i >> 31) != 0 && pnew.x == pnew.x && rect_has(K.tile, cx, cy, tc.halo))) pnew.x = __uint_as_float(0x7FC00000u);
+                }
+            }
+            count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);  // every density correction counts
+        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -724,7 +724,9 @@ struct TileDriver {
     }
 
     // ---- one solver loop (dfsph.rs:195-247 / :346-402) with the residual all-reduced over the tiles
-    int loop(bool divergence, float dt, uint32_t* out_iters, float* out_avg, uint32_t* out_warm, uint32_t* flags) {
+    // predict_first: the velocity prediction has NOT been launched — the first iteration does it on the way (sphx_sub_predict_iteration;
+    // the caller has checked that neither a warm start nor a halo exchange comes in between)
+    int loop(bool divergence, float dt, uint32_t* out_iters, float* out_avg, uint32_t* out_warm, uint32_t* flags, bool predict_first = false) {
         const uint32_t prev = divergence ? num_divergence_iters : num_density_iters;
         const uint32_t fixed = divergence ? P.fixed_divergence_iterations : P.fixed_density_iterations;
         const float tol = divergence ? P.max_divergence_error : P.max_avg_density_error;
@@ -753,7 +755,10 @@ struct TileDriver {
             if (divergence && run_ahead_ok && iters + 1 == std::max<uint32_t>(1, fixed ? fixed : prev) &&
                 std::min(avalid, std::min(valid - 2, avalid - 1)) - 1 >= 0)
                 TCHK(sphx_sub_run_ahead(ctx, dt));
-            TCHK(sphx_sub_iteration(ctx, divergence ? 1 : 0, dt, iters == 0, &s, &owned));
+            if (predict_first && iters == 0)
+                TCHK(sphx_sub_predict_iteration(ctx, dt, &s, &owned));
+            else
+                TCHK(sphx_sub_iteration(ctx, divergence ? 1 : 0, dt, iters == 0, &s, &owned));
             n_owned_local = owned;
             valid = std::min(valid - 2, avalid - 1);
             kvalid = kv;
@@ -810,9 +815,13 @@ struct TileDriver {
         s.dt_prev = step_dt_prev;
         s.dt = dt;
         s.vmax = step_vmax;
-        TCHK(sphx_sub_predict(ctx, dt));  // dfsph.rs:484-492
-        valid = std::min(avalid, valid) - 1;
-        int rc = loop(false, dt, &s.density_iterations, &s.avg_density_error, &s.warmstart_density, &s.flags);  // dfsph.rs:496
+        // dfsph.rs:484-492 — folded into the density loop's first iteration when that one follows at once: no warm start
+        // (dfsph.rs:199) and rings left for it (no halo exchange first, which would have to carry the predicted velocities)
+        const double valid_pred = std::min(avalid, valid) - 1;
+        const bool predict_first = num_density_iters <= 1 && std::min(valid_pred - 2, avalid - 1) >= 0;
+        if (!predict_first) TCHK(sphx_sub_predict(ctx, dt));
+        valid = valid_pred;
+        int rc = loop(false, dt, &s.density_iterations, &s.avg_density_error, &s.warmstart_density, &s.flags, predict_first);  // dfsph.rs:496
         if (rc) return rc;
         pending_advect_dt = dt;  // dfsph.rs:499-510 (ghosts move with their exact copies' v*): applied by the refresh() below
         steps += 1;
