@@ -545,9 +545,10 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
                                                   const uint2* __restrict__ fine, uint32_t* __restrict__ order) {
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t sl = slot[i];
-    if (sl == EMPTY) return;
-    const uint32_t p = fine[cidx[i]].x + sl;
+    // both words requested together (behind the early return the cell index was a second round trip)
+    const uint32_t sl = slot[i], ci = cidx[i];
+    if (sl == EMPTY || ci == EMPTY) return;
+    const uint32_t p = fine[ci].x + sl;
     if (p < n) order[p] = i;
 }
 
@@ -587,7 +588,13 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     if (p >= n) return;
     const uint32_t i = order[p];
     if (i >= n_in) return;
+    // The record's words are requested HERE, together with its cell index: what follows (cell range, ranking loop) is a chain of three
+    // dependent round trips the record's loads would otherwise queue behind (the early returns keep the compiler from hoisting them).
     const uint32_t ci = cidx[i];
+    float2 q = a.pos_in[i];  // the record's position as it arrives at dst
+    const float2 v = a.vel_in ? a.vel_in[i] : make_float2(0.0f, 0.0f);
+    const float r1 = a.r_in ? a.r_in[i] : 0.0f, r2 = a.r2_in ? a.r2_in[i] : 0.0f, r3 = a.r3_in ? a.r3_in[i] : 0.0f;
+    uint32_t id = a.u_in ? a.u_in[i] : 0u;
     if (ci == EMPTY) return;
     const uint2 se = fine[ci];
     const uint32_t s = se.x;
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     uint32_t dst;
     if (e - s <= RANK_LOOP_MAX) {
         uint32_t rank = 0;
-        for (uint32_t q = s; q < e; ++q) rank += (order[q] < i) ? 1u : 0u;
+        for (uint32_t k = s; k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
         dst = s + rank;
     } else {
         // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
@@ -605,9 +612,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
     }
     if (dst >= n) return;
-    float2 q = a.pos_in[i];  // the record's position as it arrives at dst
     if (a.vel_in) {
-        const float2 v = a.vel_in[i];
         if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
             q.x = q.x + v.x * a.advect_dt;
             q.y = q.y + v.y * a.advect_dt;
@@ -615,11 +620,10 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         a.vel_out[dst] = v;
     }
     a.pos_out[dst] = q;
-    if (a.r_in) a.r_out[dst] = a.r_in[i];
-    if (a.r2_in) a.r2_out[dst] = a.r2_in[i];
-    if (a.r3_in) a.r3_out[dst] = a.r3_in[i];
+    if (a.r_in) a.r_out[dst] = r1;
+    if (a.r2_in) a.r2_out[dst] = r2;
+    if (a.r3_in) a.r3_out[dst] = r3;
     if (a.u_in) {
-        uint32_t id = a.u_in[i];
         if (a.fix_owner && i < a.advect_below) {
             const uint32_t cx = sat_u16((q.x - a.gmin_x) * a.cell_inv), cy = sat_u16((q.y - a.gmin_y) * a.cell_inv);  // cell_of()
             if (!rect_has(a.own, cx, cy, 0u)) id &= 0x7FFFFFFFu;
