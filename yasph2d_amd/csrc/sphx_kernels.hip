@@ -1539,6 +1539,9 @@ __device__ __forceinline__ auto nb_stage_load(const NbHead& h, L&& load) -> NbSt
         const uint32_t t = threadIdx.x + u * 256u;
         st.w[u] = load(h.lw0 + min(t, h.lwlen ? h.lwlen - 1u : 0u));  // clamped, not predicated: no branch between the loads
     }
+    // (every table line is fetched, used or not: loading lines 64.. only for the wavefronts with more than 64 out-of-window
+    // neighbours saved 4 bytes per particle and walk at 16 M (-0.7 % of the step) and cost 3 % at 1 M — the branch waits for the
+    // wavefront's count word; profiles/r03_experiments/predict_fusion.txt section 6)
 #pragma unroll
     for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
     return st;
@@ -2119,7 +2122,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
 // correction counts, and the host clears the histogram again when another iteration follows — unless the loop is run by the device
 // (LoopArgs): then the correction derives the verdict from the residual itself and only the last one counts.
 // hist == nullptr: plain correction.
-template <bool WARM, bool INV_DT>
+template <bool WARM, bool INV_DT, bool TILE = false>
 __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __restrict__ posA, const float* __restrict__ kbuf,
                                                   float* __restrict__ warm, uint32_t n,
                                                   uint32_t soff, Consts K, float inv_dt, float lim, NbView nb,
@@ -2174,7 +2177,8 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
     // nothing is read, and nobody had to write that zero either
     const float warm_i = (i < n && !first) ? warm[i] : 0.0f;
-    const uint32_t id_i = (!WARM && INV_DT && tc.pid && i < n) ? tc.pid[i] : 0u;
+    // (TILE — TileClassArgs in use: clamped, not predicated; behind a branch the compiler tests the owner bit inside it and waits there)
+    const uint32_t id_i = TILE ? tc.pid[min(i, n - 1u)] : 0u;
     struct StageRec {
         float2 p;
         float w;
@@ -2270,7 +2274,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     }
     if (!WARM && INV_DT)
         if (ca.hist) {
-            if (tc.pid) {  // tile: k_tile_count's and k_tile_pack's verdicts, from the position in registers
+            if (TILE) {  // k_tile_count's and k_tile_pack's verdicts, from the position in registers
                 __shared__ uint32_t wc[4][MAX_TILE_PEERS];
                 const uint32_t m = i < n ? tile_send_mask(K, tc.rect, tc.n, tc.halo, make_float4(pnew.x, pnew.y, 0.0f, 0.0f), id_i) : 0u;
                 for (uint32_t k = 0; k < tc.n; ++k) {
