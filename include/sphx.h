@@ -45,7 +45,8 @@ extern "C" {
 
 #define SPHX_ABI_VERSION 3 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
                             * 3: sphx_comm_ops.abort, sphx_multi_info_t list statistics, sphx_shm_abort (and sphx_shm_open as a collective),
-                            *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect, sphx_sub_predict_iteration */
+                            *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect, sphx_sub_predict_iteration, sphx_tile_band_packs,
+                            *    sphx_multi_info_t.band_packs (was reserved) */
 
 /* ---- status codes ---- */
 enum {
@@ -265,6 +266,10 @@ int sphx_tile_carry_warmstart(sphx_ctx* ctx, int kappa, int stiffness);
  * gather, which applies the same x += v* dt while it moves them (24 bytes per particle less in the packing pass).  Any other entry
  * point that looks at the records in between applies the pending advection first. */
 int sphx_tile_defer_advect(sphx_ctx* ctx, int on);
+/* Tile mode statistics: halo packs (sphx_tile_advect_pack_n) that found their particles classified by the density loop's last
+ * correction — send counts per workgroup, kept / retired, cell count (SPHX_TILE_FUSE_CLASS=0 turns that off) — and only visited
+ * the workgroups that send something. */
+int sphx_tile_band_packs(const sphx_ctx* ctx, uint32_t* out);
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */
@@ -306,7 +311,8 @@ typedef struct sphx_comm_ops {
 typedef struct sphx_multi_info_t {
     uint32_t world, local_tiles, halo_now, halo_max, peers, n_local, cap_records, grid_layout;
     int32_t axis;
-    uint32_t reserved;
+    uint32_t band_packs; /* of tile 0's halo exchanges: how many packed from the classification its last density correction had made
+                            (only the workgroups inside a send band were visited again) */
     uint64_t exchanges, rebalances;
     /* the local tiles' latest neighbour build (measured, not assumed): particles it ran over (owned + ghosts), list entries, and
      * entries outside the workgroup windows — mean list length = neighbor_entries / build_particles */

@@ -331,3 +331,91 @@ def test_sphx_multi_four_tiles_at_4M_against_the_single_context():
     assert abs(kbar_tiles - kbar_single) < 0.15, (kbar_tiles, kbar_single)  # (ghosts at the rim of the band have shorter lists)
     assert 0 < info["remote_entries"] < info["neighbor_entries"]
     m.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_tile_classification_by_the_last_density_correction_changes_nothing(monkeypatch, overlap):
+    """The density loop's last correction holds the advected positions: in a tile it counts the cells of the particles the tile keeps
+    and the records to send (TileClassArgs), the packing pass then visits only the workgroups inside a send band, the re-grid's gather
+    clears the owner bit of new ghosts.  SPHX_TILE_FUSE_CLASS=0: k_tile_count + k_tile_pack read every particle again.  2 x 2 tiles
+    through the impact with adaptive iteration counts (warm starts, extra exchanges in the middle of a loop, re-partitioning, band
+    adaptation — each of which makes single steps fall back): same bits, counts, exchanges; and the fused path was the usual one."""
+    pos, boundary = dam_break(2.0)
+    lay = GridLayout.quantile(pos, 2, 2)
+
+    def run(fused):
+        monkeypatch.setenv("SPHX_TILE_FUSE_CLASS", "1" if fused else "0")
+        m = MultiSolver(y.default_params(), devices=[0, 0, 0, 0], halo=10, rebalance_every=6, overlap_exchange=overlap)
+        m.set_grid(lay.xcuts, lay.ycuts)
+        m.set_boundary(boundary)
+        m.upload(pos)
+        timer = y.TimeManager()
+        stats = [m.step(timer) for _ in range(140)]
+        out = by_id({k: v for k, v in m.download().items() if k in ("ids", "pos", "vel", "density")})
+        return out, [(s["density_iterations"], s["divergence_iterations"], s["dt_ns"]) for s in stats], m.info()
+
+    a, ca, ia = run(True)
+    b, cb, ib = run(False)
+    assert ca == cb and ia["exchanges"] == ib["exchanges"] and ia["rebalances"] == ib["rebalances"]
+    np.testing.assert_array_equal(a["ids"], b["ids"])
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+    assert ib["band_packs"] == 0
+    assert ia["band_packs"] > 100, ia  # (140 steps; the steps with a re-partitioning or a new band width pack the long way)
+
+
+def test_classified_tile_step_survives_a_call_between_pack_and_regrid():
+    """Sub-step ABI: after a pack that used the density correction's classification the advection of the kept records, the owner
+    bits of the new ghosts and the retirement of what left the band are all pending in the re-grid's gather.  A caller that looks at
+    the records first (here: a download) must find them applied, and the re-grid behind it must end in the same state."""
+    import torch
+
+    L = _lib.lib()
+    pos, boundary = dam_break(1.0)
+    cx = cell_coord(pos, 0)
+    cut = int(np.sort(cx)[len(cx) // 2])
+    rect = C.c_uint32 * 4
+    mine = np.nonzero(cx < cut)[0]
+    p = np.ascontiguousarray(pos[mine], np.float32)
+    v = np.zeros_like(p)
+    v[:, 0] = 3.0     # everything drifts towards the cut: owned particles cross it and stay as ghosts ...
+    v[::53, 0] = 90.0  # ... and some jump over the whole ghost band: retired
+    ids = mine.astype(np.uint32)
+    dt = np.float32(0.004)
+    cap = 20000
+    res = {}
+    for mode in ("regrid", "flush"):
+        ctx = y.SphxContext()
+        h = ctx.h
+        ctx.set_boundary(boundary)
+        assert L.sphx_tile_configure_rect(h, rect(0, cut, 0, 65536), 8, (rect * 1)(rect(cut, 65536, 0, 65536)), 1) == 0
+        assert L.sphx_tile_defer_advect(h, 1) == 0
+        assert L.sphx_reserve(h, len(mine) + cap) == 0
+        q = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert L.sphx_tile_upload(h, q(p), q(v), q(ids), len(mine)) == 0
+        n = C.c_uint32()
+        assert L.sphx_sub_regrid(h, C.byref(n)) == 0 and n.value == len(mine)
+        vsq = C.c_float()
+        assert L.sphx_sub_nonpressure(h, dt, C.byref(vsq)) == 0
+        s_, owned = C.c_double(), C.c_uint64()
+        assert L.sphx_sub_predict_iteration(h, dt, C.byref(s_), C.byref(owned)) == 0 and owned.value == len(mine)
+        send = torch.zeros((1 + cap) * 32, dtype=torch.uint8, device="cuda")
+        bufs = (C.c_void_p * 1)(send.data_ptr())
+        assert L.sphx_tile_advect_pack_n(h, dt, bufs, 1, cap) == 0
+        packs = C.c_uint32()
+        assert L.sphx_tile_band_packs(h, C.byref(packs)) == 0 and packs.value == 1
+        if mode == "flush":
+            res["flush_pos"] = ctx.download(density=False)["pos"].copy()  # looks at the records: the pending work is applied first
+        assert L.sphx_sub_regrid(h, C.byref(n)) == 0
+        d = ctx.download(density=False)
+        res[mode] = (n.value, {k: d[k][np.argsort(d["ids"] & 0x7FFFFFFF, kind="stable")] for k in ("ids", "pos", "vel")}, send.cpu().numpy().copy())
+        ctx.close()
+    na, a, sa = res["regrid"]
+    nb, b, sb = res["flush"]
+    assert na == nb < len(mine) and np.array_equal(sa, sb)
+    np.testing.assert_array_equal(a["ids"], b["ids"])  # (owner bits included)
+    assert_bits_equal(a["pos"], b["pos"], "pos")
+    assert_bits_equal(a["vel"], b["vel"], "vel")
+    assert 0 < (a["ids"] >> 31).sum() < na            # some owned particles crossed the cut and stayed as ghosts
+    assert np.isnan(res["flush_pos"][:, 0]).sum() == len(mine) - na  # the ones that left the band: retired by the flush already
+    assert int(np.frombuffer(sa[16:20].tobytes(), np.uint32)[0]) > 0   # header of the send buffer: records went out

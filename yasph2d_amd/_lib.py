@@ -96,7 +96,7 @@ class SphxCommOps(C.Structure):
 
 class SphxMultiInfo(C.Structure):
     _fields_ = [("world", C.c_uint32), ("local_tiles", C.c_uint32), ("halo_now", C.c_uint32), ("halo_max", C.c_uint32), ("peers", C.c_uint32),
-                ("n_local", C.c_uint32), ("cap_records", C.c_uint32), ("grid_layout", C.c_uint32), ("axis", C.c_int32), ("reserved", C.c_uint32),
+                ("n_local", C.c_uint32), ("cap_records", C.c_uint32), ("grid_layout", C.c_uint32), ("axis", C.c_int32), ("band_packs", C.c_uint32),
                 ("exchanges", C.c_uint64), ("rebalances", C.c_uint64), ("build_particles", C.c_uint64), ("neighbor_entries", C.c_uint64),
                 ("remote_entries", C.c_uint64), ("owned_local", C.c_uint64), ("transport", C.c_char * 96)]
 
@@ -148,6 +148,7 @@ SIGNATURES = {
     "sphx_sub_warmstart": (_i, [_vp, _i, _f]),
     "sphx_sub_iteration": (_i, [_vp, _i, _f, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "sphx_sub_predict_iteration": (_i, [_vp, _f, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "sphx_tile_band_packs": (_i, [_vp, C.POINTER(_u32)]),
     "sphx_sub_advect": (_i, [_vp, _f]),
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -309,6 +309,8 @@ struct sphx_ctx {
     // tile path: the last density correction classifies its particles for the halo exchange (TileClassArgs; SPHX_TILE_FUSE_CLASS=0: off)
     int tile_fuse_class = 1;
     bool tile_class_done = false;   // ... has happened, for tile_class_n particles advected by the dt with these bits
+    uint32_t tile_band_packs = 0;   // statistics: sphx_tile_band_packs
+    bool count_from_class = false;  // the fused cell count on the device is that correction's (drop_class_count)
     uint32_t tile_class_n = 0, tile_class_dt_bits = 0;
     bool tile_fix_owner = false;    // the re-grid's gather clears the owner bit of kept particles that left the own rectangle
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build

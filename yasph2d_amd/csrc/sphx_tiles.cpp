@@ -496,7 +496,9 @@ struct TileDriver {
             return fail(SPHX_ERR_HIP, "hipStreamCreate / hipEventCreate");
         // the tile's kernels and its communication share one stream: pack -> exchange -> unpack are ordered by the stream
         TCHK(sphx_set_stream(ctx, stream));
-        TCHK(sphx_tile_defer_advect(ctx, overlap ? 0 : 1));  // (with the exchange on a second stream the kept particles are counted from their records)
+        // the kept particles' advection rides on the re-grid's gather (with the exchange on a second stream too: the cells of the kept
+        // particles are counted by the density loop's last correction or by the packing pass, not from their records)
+        TCHK(sphx_tile_defer_advect(ctx, 1));
         bufs.assign(comm->world, {nullptr, nullptr});
         return SPHX_OK;
     }
@@ -1176,6 +1178,7 @@ int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out) {
     out->peers = (uint32_t)t.peers.size();
     out->exchanges = t.exchanges;
     out->rebalances = t.rebalances;
+    sphx_tile_band_packs(t.ctx, &out->band_packs);
     out->n_local = t.n_local;
     out->cap_records = t.cap;
     out->grid_layout = t.layout.axis < 0;
