@@ -43,15 +43,16 @@ def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, fo
     return 252 + 16 * kbar + Id * (84 + 8 * kbar) + Iv * (80 + 8 * kbar) + (Wd + Wv) * (44 + 4 * kbar) - folded * lst
 
 
-def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=True, fuse_div=True):
+def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=True, fuse_div=True, fuse_predict=True):
     """Per-particle-step bytes of THIS build's arrays (each per-particle array a pass touches, once; neighbour records
     assumed cache-served) — smaller than the SURVEY.md §8(d) model above, which prices the reference's array set: positions and
     velocities are separate 8-byte arrays (a velocity-only pass moves 8 bytes, not 16), the first correction of a loop neither reads
     nor zeroes the warm-start value, the divergence loop's first compute_density_change (or its warm start) rides on the neighbour
-    build, and a list is 2 + 4/3 k + 4 r bytes."""
+    build, the velocity prediction on the density loop's first compute_density_error when no warm start precedes it (the acceleration
+    read and the velocity written there: 16 bytes instead of a pass of 24), and a list is 2 + 4/3 k + 4 r bytes."""
     L = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     nonpressure = 16 + 4 + L + 8
-    predict = 24
+    predict = (24 * min(Wd, 1.0) + 16 * (1.0 - min(Wd, 1.0))) if fuse_predict else 24
     dens_iter_first = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 4 + 8)   # compute_error + correction (+ the re-grid's cell count: 8)
     dens_iter_more = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 8 + 8)
     regrid = 6 + 20 + 50                                                  # scan (per particle, dam-break table), scatter, gather
@@ -447,7 +448,8 @@ def main():
         bstep_ref = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"])
         bstep = bytes_per_particle_step(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], compressed=not args.lists_32bit, rbar=rb, folded=folded)
         blay = bytes_per_particle_step_this_build(kb, it["Id"], it["Iv"], it["Wd"], it["Wv"], rb, compressed=not args.lists_32bit,
-                                                   fuse_div=fuse_div and args.solver == "dfsph")
+                                                   fuse_div=fuse_div and args.solver == "dfsph",
+                                                   fuse_predict=os.environ.get("SPHX_FUSE_PREDICT", "1") != "0" and not args.no_device_dt and not args.force_tiles)
         return {"bytes_per_particle_step": bstep, "bytes_per_particle_step_32bit_lists": bstep_ref,
                 "bytes_per_particle_step_this_build": blay,
                 "bytes_note": "bytes_per_particle_step = SURVEY.md 8(d)'s list-based model of the reference's array set (what frac_of_hbm_peak_whole_step "

@@ -11,8 +11,13 @@ NAMES = {  # kernel symbol -> bench.py's launch label
     "k_neighbor_build<true>": "neighbor_build+density_alpha", "k_neighbor_build<1>": "neighbor_build+density_alpha",
     "k_neighbor_build<2>": "neighbor_build+density_alpha+density_change", "k_neighbor_build<3>": "neighbor_build+density_alpha+divergence_warmstart", "k_neighbor_build<0>": "neighbor_build", "k_nonpressure": "nonpressure_accel_vmax",
     "k_compute_error<false>": "compute_density_error", "k_compute_error<true>": "compute_density_change",
+    "k_compute_error<false, false>": "compute_density_error", "k_compute_error<true, false>": "compute_density_change",
+    "k_compute_error<false, true>": "velocity_prediction+compute_density_error",
     "k_correct<false, true>": "correct_velocity_with_density_error", "k_correct<false, false>": "correct_velocity_with_divergence_error",
     "k_correct<true, true>": "correct_density_error_warmstart", "k_correct<true, false>": "correct_divergence_error_warmstart",
+    "k_correct<false, true, false>": "correct_velocity_with_density_error", "k_correct<false, true, true>": "correct_velocity_with_density_error",
+    "k_correct<false, false, false>": "correct_velocity_with_divergence_error",
+    "k_correct<true, true, false>": "correct_density_error_warmstart", "k_correct<true, false, false>": "correct_divergence_error_warmstart",
     "k_rank_gather": "gather_attributes", "k_key_count<true>": "advect+cell_count", "k_predict": "velocity_prediction", "k_scatter": "cell_scatter",
 }
 
