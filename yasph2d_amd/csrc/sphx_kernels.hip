@@ -1732,6 +1732,20 @@ __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict
     const uint32_t m = block_max_u32(__float_as_uint(vsq));
     if (threadIdx.x == 0 && m) atomicMax(&scal->vstripe[blockIdx.x % STRIPES].vmax[vslot & 3u], m);
 }
+// The same with the four per-wavefront words in memory the caller has finished with (k_nonpressure: its staging area is 20 KiB to
+// the byte — with 16 bytes of its own for this reduction a workgroup no longer fits eight times into the CU's 160 KiB).
+__device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict__ scal, uint32_t vslot, uint32_t* wm) {
+    uint32_t b = __float_as_uint(vsq);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
+    __syncthreads();  // every wavefront has left the staging area
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m) atomicMax(&scal->vstripe[blockIdx.x % STRIPES].vmax[vslot & 3u], m);
+    }
+}
 // called by a whole wavefront; every lane returns the maximum
 __device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1829,7 +1843,10 @@ __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs 
 // ------------------------------------------------------------------------------------------------------------------
 // a10 + a11: non-pressure acceleration with XSPH (dfsph.rs:436-469, xsph.rs:21-23) and max |v + a*dt|^2 (dfsph.rs:474-477)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ TRAV_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
+#ifndef NONP_BOUNDS
+#define NONP_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+__global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ float4 rec[STAGE_SLOTS];
     __shared__ float rho_s[STAGE_SLOTS];
@@ -1872,7 +1889,7 @@ __global__ TRAV_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
-    block_vmax_add(vsq, scal, vslot);
+    block_vmax_add(vsq, scal, vslot, (uint32_t*)rho_s);
 }
 
 // a12: dfsph.rs:484-492 — vel[] becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
