@@ -410,13 +410,8 @@ def main():
         if live is not None and live["launches"]:
             ev_ms = ctx.profile_event_overhead()  # what an EMPTY hipEvent bracket measures on this stream, same process
             avg_raw = live["total_ms"] / live["launches"]
-            # NOT corrected by the empty bracket: the marker latency an empty bracket shows (~4.6 us) is hidden behind the kernel when there
-            # is one in between — the bracketed time agrees with rocprofv3's kernel trace of the same command to ~1 % (profiles/
-            # r03_stats_*.txt; the sum of the trace's durations is the un-profiled step time), the "corrected" one was 10 % short
-            avg_ms = avg_raw
-            ach = live["bytes"] / live["launches"] / (avg_ms * 1e-3) / 1e9
             traffic, traffic_src = traffic_of(dominant, n)
-            # per-kernel table (information only): a short extra pass with every launch timed, outside the timed region
+            # per-kernel table: a short extra pass with every launch timed, outside the timed region
             ctx.profile_reset()
             ctx.profile_enable(True)
             extra = max(10, min(steps, 30))
@@ -424,15 +419,27 @@ def main():
                 one_step()
             ctx.profile_enable(False)
             prof = ctx.profile_get()
+            # What a bracket adds to the kernel inside it, measured on this very run: with EVERY launch bracketed the brackets of a step
+            # add up to more than the (gap-free) un-bracketed step takes — the difference, spread over the step's launches, is the
+            # inflation per bracket (~1.5 us at 1 M).  (Not the empty bracket: the ~4.6 us marker latency an empty bracket shows hides
+            # behind the kernel when there is one in between; subtracting it made the figure 7 % shorter than rocprofv3's kernel trace.
+            # With this correction the two agree to ~1 %: profiles/r03_stats_*.txt.)
+            sum_bracketed = sum(v["total_ms"] for v in prof.values()) / extra
+            per_step = sum(v["launches"] for v in prof.values()) / extra
+            infl = max(0.0, (sum_bracketed - elapsed * 1e3 / steps) / per_step) if per_step else 0.0
+            infl = min(infl, ev_ms)
+            avg_ms = max(avg_raw - infl, 1e-6)
+            ach = live["bytes"] / live["launches"] / (avg_ms * 1e-3) / 1e9
             roof = {
                 "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_achievable_6300": ach / HBM_ACHIEVABLE_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms,
-                "empty_event_bracket_ms": ev_ms, "avg_launch_ms_minus_empty_bracket": max(avg_raw - ev_ms, 1e-6), "launches": live["launches"],
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "avg_launch_ms_bracketed": avg_raw,
+                "bracket_inflation_ms": infl, "empty_event_bracket_ms": ev_ms, "launches": live["launches"],
                 "algorithmic_bytes_per_launch": live["bytes"] / live["launches"],
-                "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream (uncorrected; "
-                            "an EMPTY bracket in the same process measures empty_event_bracket_ms — information only)" if live_from == "timed region" else
-                            "hipEvents around this kernel's launches (uncorrected); taken from the " + live_from,
+                "measured": "hipEvents around every 4th launch of this kernel inside the timed region, on the context's stream, minus "
+                            "bracket_inflation_ms = (sum of all bracketed launches of a step - the un-bracketed step) / launches per step, from "
+                            "a pass with every launch bracketed" if live_from == "timed region" else
+                            "hipEvents around this kernel's launches, minus bracket_inflation_ms; taken from the " + live_from,
                 "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
                 "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (which keeps kernels from overlapping their "
                         "neighbours' tails): its sum exceeds ms_per_step; information only",

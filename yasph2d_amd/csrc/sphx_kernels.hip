@@ -58,6 +58,29 @@ __device__ __forceinline__ uint32_t dir_entry(const GridView& g, uint32_t x, uin
     if (bx >= g.nbx || by >= g.nby) return EMPTY;
     return g.dir[by * g.nbx + bx];
 }
+// The same for a caller that requested the entry of a block early (DirAhead: the block its particle WAS in — almost always the
+// block it is still in): the load at the end of the kernel, one more round trip in every workgroup's tail, only happens for the few
+// lanes whose particle changed block.
+struct DirAhead {
+    uint32_t blk;    // by * nbx + bx of the block looked up, 0xFFFFFFFF: none
+    uint32_t entry;
+};
+__device__ __forceinline__ DirAhead dir_ahead(const GridView& g, uint32_t x, uint32_t y) {
+    const uint32_t bx = (x >> BLOCK_SHIFT) - g.bx0, by = (y >> BLOCK_SHIFT) - g.by0;
+    DirAhead a{0xFFFFFFFFu, EMPTY};
+    if (bx < g.nbx && by < g.nby) {
+        a.blk = by * g.nbx + bx;
+        a.entry = g.dir[a.blk];
+    }
+    return a;
+}
+__device__ __forceinline__ uint32_t dir_entry(const GridView& g, uint32_t x, uint32_t y, const DirAhead& a) {
+    const uint32_t bx = (x >> BLOCK_SHIFT) - g.bx0, by = (y >> BLOCK_SHIFT) - g.by0;
+    if (bx >= g.nbx || by >= g.nby) return EMPTY;
+    const uint32_t blk = by * g.nbx + bx;
+    if (blk == a.blk) return a.entry;
+    return g.dir[blk];
+}
 // index of cell (x,y) (Morton code `code`) in the fine table, or EMPTY if its 64x64 block is not in the directory
 __device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uint32_t y, uint32_t code) {
     const uint32_t off = dir_entry(g, x, y);
@@ -478,7 +501,8 @@ struct CountArgs {
 // cidx[i] = the particle's index into the fine table (kept for scatter/gather).
 // Called by ALL lanes of a wavefront (live = this lane holds particle i at position p).
 __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, bool live, uint32_t i, float2 p, uint32_t* __restrict__ hist,
-                                           uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring, DevScalars* __restrict__ scal) {
+                                           uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring, DevScalars* __restrict__ scal,
+                                           const DirAhead ahead = DirAhead{0xFFFFFFFFu, EMPTY}) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = EMPTY;
     if (live) {
@@ -487,7 +511,7 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
         const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
         uint32_t f = 0;
         const uint32_t code = morton2(cx, cy);
-        const uint32_t entry = dropped ? EMPTY : dir_entry(g, cx, cy);
+        const uint32_t entry = dropped ? EMPTY : dir_entry(g, cx, cy, ahead);
         idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
         if (!dropped) {
             if (entry == EMPTY) {
@@ -2200,16 +2224,28 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         float2 p;
         float w;
     };
-    nb_stage(
-        h,
-        [&](uint32_t g) {
-            // warm[] / kbuf[] have no boundary tail; static entries do not use the scalar
-            return StageRec{gat(posA, g), gat(wsrc, g < soff ? g : 0u)};
-        },
-        [&](uint32_t slot, const StageRec& q) {
-            pos_s[slot] = q.p;
-            w_s[slot] = q.w;
-        });
+    auto load_rec = [&](uint32_t g) {
+        // warm[] / kbuf[] have no boundary tail; static entries do not use the scalar
+        return StageRec{gat(posA, g), gat(wsrc, g < soff ? g : 0u)};
+    };
+    auto store_rec = [&](uint32_t slot, const StageRec& q) {
+        pos_s[slot] = q.p;
+        w_s[slot] = q.w;
+    };
+    DirAhead ahead{0xFFFFFFFFu, EMPTY};
+    if (!WARM && INV_DT && ca.hist) {
+        // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, with the
+        // staging loads in flight, for the block the particle is in BEFORE it moves (a particle rarely changes its 64 x 64 block)
+        const NbStaged<StageRec> st = nb_stage_load(h, load_rec);
+        if (i < n) {
+            uint32_t cx0, cy0;
+            cell_of(K, make_float2(pvi.x, pvi.y), cx0, cy0);
+            ahead = dir_ahead(ca.g, cx0, cy0);
+        }
+        nb_stage_store(h, st, [&](uint32_t slot, const StageRec& q, uint32_t) { store_rec(slot, q); });
+    } else {
+        nb_stage(h, load_rec, store_rec);
+    }
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
         residual_wave_reduce(hi, lo);
@@ -2313,7 +2349,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
                     if (!((id_i >> 31) != 0 && pnew.x == pnew.x && rect_has(K.tile, cx, cy, tc.halo))) pnew.x = __uint_as_float(0x7FC00000u);
                 }
             }
-            count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal);  // every density correction counts
+            count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal, ahead);  // every density correction counts
         }
 }
 
