@@ -611,6 +611,13 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     const uint32_t p = xcd_bid() * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t i = order[p];
+    // the slots around p, requested in the same round trip: a cell holds two or three particles, so the cell mates the ranking loop
+    // below looks at are almost always among them — and that loop's loads, which depend on the cell range (itself two dependent
+    // loads away), no longer are a round trip of their own
+    constexpr int RANK_WIN = 3;
+    uint32_t near[2 * RANK_WIN + 1];
+#pragma unroll
+    for (int d = -RANK_WIN; d <= RANK_WIN; ++d) near[d + RANK_WIN] = order[(uint32_t)min(max((int32_t)p + d, 0), (int32_t)n - 1)];
     if (i >= n_in) return;
     // The record's words are requested HERE, together with its cell index: what follows (cell range, ranking loop) is a chain of three
     // dependent round trips the record's loads would otherwise queue behind (the early returns keep the compiler from hoisting them).
@@ -627,7 +634,14 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     uint32_t dst;
     if (e - s <= RANK_LOOP_MAX) {
         uint32_t rank = 0;
-        for (uint32_t k = s; k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
+#pragma unroll
+        for (int d = -RANK_WIN; d <= RANK_WIN; ++d) {
+            const int32_t k = (int32_t)p + d;
+            rank += (k >= (int32_t)s && k < (int32_t)e && near[d + RANK_WIN] < i) ? 1u : 0u;
+        }
+        // (whatever the cell holds outside the window)
+        for (uint32_t k = s; k + RANK_WIN < p && k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
+        for (uint32_t k = max(s, p + RANK_WIN + 1u); k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
         dst = s + rank;
     } else {
         // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
