@@ -2348,13 +2348,6 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
                     const uint32_t c = (uint32_t)__popcll(__ballot((m >> k) & 1u));
                     if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6][k] = c;
                 }
-                __syncthreads();
-                if (threadIdx.x < 64) {
-                    const uint32_t v = threadIdx.x < tc.n ? wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x] : 0u;
-                    if (threadIdx.x < MAX_TILE_PEERS) tc.blk[(size_t)blk * MAX_TILE_PEERS + threadIdx.x] = v;
-                    const unsigned long long sends = __ballot(v != 0u);
-                    if (threadIdx.x == 0) tc.any[blk] = sends ? 1u : 0u;
-                }
                 if (i < n) {
                     // what the tile keeps: its own particles (owner bit) that are still inside the rectangle grown by the ghost band;
                     // last step's ghosts and whatever left the band get no cell (k_tile_pack marked those with a NaN position)
@@ -2362,6 +2355,19 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
                     cell_of(K, pnew, cx, cy);
                     if (!((id_i >> 31) != 0 && pnew.x == pnew.x && rect_has(K.tile, cx, cy, tc.halo))) pnew.x = __uint_as_float(0x7FC00000u);
                 }
+                count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal, ahead);
+                // (the send counts last: the barrier they need then only holds back wavefronts that have nothing left to do; a tile
+                // without neighbours has none to write)
+                if (tc.n) {
+                    __syncthreads();
+                    if (threadIdx.x < 64) {
+                        const uint32_t v = threadIdx.x < tc.n ? wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x] : 0u;
+                        if (threadIdx.x < MAX_TILE_PEERS) tc.blk[(size_t)blk * MAX_TILE_PEERS + threadIdx.x] = v;
+                        const unsigned long long sends = __ballot(v != 0u);
+                        if (threadIdx.x == 0) tc.any[blk] = sends ? 1u : 0u;
+                    }
+                }
+                return;
             }
             count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal, ahead);  // every density correction counts
         }
