@@ -726,7 +726,8 @@ def main():
                 f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
                 f"particle-count quantiles), step loop inside libsphx (sphx_multi), ghost halo {minfo['halo_now']} of <= {args.halo} cells (follows "
                 f"the ring budget), per step: 1 halo exchange with {minfo['peers']} neighbours + 3 scalar all-reduces; transport: "
-                f"{minfo['transport']}; {minfo['exchanges']} exchanges and {minfo['rebalances']} re-partitions in total",
+                f"{minfo['transport']}; {minfo['exchanges']} exchanges ({minfo['band_packs']} of them packed from the density correction's "
+                f"classification: only the send bands were visited again) and {minfo['rebalances']} re-partitions in total",
                 "mean_density_iterations": it["Id"], "mean_divergence_iterations": it["Iv"], "warmstart_rate": [it["Wd"], it["Wv"]], "mean_neighbors": kbar,
                 "max_density_iterations_seen": it["Id_max"], "max_divergence_iterations_seen": it["Iv_max"],
                 "host_calls": "one library call runs the K timed steps (sphx_*_simulation_steps: the caller's frame loop, main.rs:348-350, "
