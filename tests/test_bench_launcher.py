@@ -73,3 +73,23 @@ def test_two_ranks_share_the_gpu_over_gloo():
     assert 6.0 < d["config"]["mean_neighbors"] < 14.0 and d["step_model"]["k_and_r"].startswith("measured")
     assert len(d["config"]["owned_particles_per_rank"]) == 2 and sum(d["config"]["owned_particles_per_rank"]) == d["config"]["particles_total"]
     assert "transport" in d["config"]
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_2x2_tiles_share_the_gpu_over_gloo():
+    """configs[3]'s layout through the launcher-free multi-rank path: 4 ranks = 2 x 2 tiles (three neighbours each, diagonal ones
+    included) on the one GPU of the box, halo records staged through gloo; most exchanges packed from the density correction's
+    classification."""
+    rc, out, err = run(["--gpus", "4", "--backend", "gloo", "--particles", "60000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"])
+    assert rc == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["world_size_seen"] == 4 and d["value"] > 0
+    c = d["config"]
+    assert "2 x N/2" in c["parallelism"] and "3 neighbours" in c["parallelism"], c["parallelism"]
+    assert len(c["owned_particles_per_rank"]) == 4 and sum(c["owned_particles_per_rank"]) == c["particles_total"]
+    assert 6.0 < c["mean_neighbors"] < 14.0
+    packed = int(c["parallelism"].split(" exchanges (")[1].split(" ")[0])
+    total = int(c["parallelism"].split(" exchanges (")[0].split(" ")[-1])
+    assert total >= 14 and packed >= total - 4, c["parallelism"]
