@@ -111,6 +111,21 @@ struct GridView {
     const uint2* fine;  // {first sorted particle of the cell, one past its last}
     uint32_t bx0, by0, nbx, nby;
 };
+// The same grid as the neighbour build reads it (round 4): a second directory `dirn` in which NO entry is special —
+//   * a block the directory does not cover points at the NULL BLOCK, 4096 all-zero entries behind the cell table ({0, 0}: an empty
+//     range), so the nine look-ups of a 3x3 box need no "is it covered" select, neither on the slot nor on the range;
+//   * block coordinates outside the directory's rectangle are CLAMPED into it (nbx1 = nbx - 1, nby1 = nby - 1) instead of tested:
+//     what such a look-up finds are the cells of some other block with the same local coordinates — 60 or more cells away, every
+//     candidate fails the distance test, and a cell never aliases one of the box's own (their local coordinates differ);
+//   * bit 0 (DIRN_FLAG) of an entry — dynamic grid: the boundary's directory covers this block or one of its eight neighbours
+//     (only then can a particle of the block have static neighbours; null entries carry it always); static grid: the block is covered.
+// An empty directory is presented as one null entry.
+struct NbGrid {
+    const uint32_t* dirn;
+    const uint2* fine;
+    uint32_t bx0, by0, nbx, nbx1, nby1;
+};
+constexpr uint32_t DIRN_FLAG = 1u;
 
 struct alignas(128) Stripe {
     unsigned long long nb_entries;  // partial sum of count_total over ALL builds so far (stats only; the host takes differences)
@@ -203,8 +218,9 @@ struct TimerLaw {
 
 struct Grid {
     uint32_t* dir = nullptr;   // nbx*nby entries
+    uint32_t* dirn = nullptr;  // the neighbour build's form of it (NbGrid), max(nbx*nby, 1) entries
     uint32_t dir_cap = 0;
-    uint2* fine = nullptr;     // cell ranges of the latest build (len() entries)
+    uint2* fine = nullptr;     // cell ranges of the latest build (len() entries) + the null block (BLOCK_CELLS all-zero entries)
     uint32_t* hist = nullptr;  // all-zero between builds; receives the next build's per-cell histogram
     uint32_t fine_cap = 0;     // entries allocated in fine and hist
     uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
@@ -213,6 +229,7 @@ struct Grid {
     bool fine_valid = false;      // `fine` holds the cell ranges of a build made with THIS directory
     uint32_t len() const { return nblk * BLOCK_CELLS; }
     GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
+    NbGrid nview() const { return nbx && nby ? NbGrid{dirn, fine, bx0, by0, nbx, nbx - 1u, nby - 1u} : NbGrid{dirn, fine, 0u, 0u, 1u, 0u, 0u}; }
 };
 
 struct ProfTotals {

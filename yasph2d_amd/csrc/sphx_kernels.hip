@@ -171,6 +171,43 @@ __device__ __forceinline__ float4 ldpv(const PVr& v, uint32_t idx) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Wave-wide reductions on the DPP data path (round 4).  A __shfl_xor butterfly is six ds_bpermute round trips with four vector
+// instructions of lane arithmetic each (thirty per reduction, sixty for a 64-bit value); here a step is ONE vector instruction
+// whose second operand is read from another lane: two quad permutes and two mirrors leave the total of a row of 16 in every lane of
+// the row, two row broadcasts carry it into lane 63, a v_readlane hands it to the scalar unit — seven instructions, result
+// wave-uniform in a scalar register.  Call with the WHOLE wavefront active (a DPP read of an inactive lane yields the identity).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // (the total must fit 32 bits)
+    v += dpp_mov<DPP_QUAD_1032>(0u, v);
+    v += dpp_mov<DPP_QUAD_2301>(0u, v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(0u, v);
+    v += dpp_mov<DPP_ROW_MIRROR>(0u, v);
+    v += dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v);
+    v += dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_mov<DPP_QUAD_1032>(0u, v));
+    v = max(v, dpp_mov<DPP_QUAD_2301>(0u, v));
+    v = max(v, dpp_mov<DPP_ROW_HALF_MIRROR>(0u, v));
+    v = max(v, dpp_mov<DPP_ROW_MIRROR>(0u, v));
+    v = max(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v));
+    v = max(v, dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// exact sum of 64 values below 2^62 each... as three limbs of 21 bits (their sums stay below 2^27), recombined on the scalar unit
+__device__ __forceinline__ unsigned long long wave_sum_u63(unsigned long long f) {
+    const uint32_t lo = (uint32_t)f, hi = (uint32_t)(f >> 32);
+    const uint32_t a = lo & 0x1FFFFFu, b = (uint32_t)(f >> 21) & 0x1FFFFFu, c = hi >> 10;  // c < 2^22 for f < 2^64: 64 of them < 2^28
+    return (unsigned long long)wave_sum_u32(a) + ((unsigned long long)wave_sum_u32(b) << 21) + ((unsigned long long)wave_sum_u32(c) << 42);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // device-wide exclusive scan (reduce / scan-partials / apply), length may live on the device
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
@@ -964,8 +1001,8 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
 
 // Fine-table slots of the 3x3 cell box around (cx, cy), ascending.  The fine table is in global Morton order (blocks ranked in
 // Morton order, cells inside a block by the low 12 bits of their code), so sorting the SLOTS sorts the cells by Morton code —
-// no 32-bit codes, no de-interleaving of block coordinates.  Cells in blocks the directory does not cover get EMPTY and sort to
-// the end.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit positions.
+// no 32-bit codes, no de-interleaving of block coordinates.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit
+// positions.
 __device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2,4,6,8,10
     v &= 63u;
     v = (v | (v << 4)) & 0x30Fu;
@@ -973,18 +1010,17 @@ __device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2
     v = (v | (v << 1)) & 0x555u;
     return v;
 }
-// maybe_static (dynamic grid only): true when one of the nine blocks carries DIR_STATIC or is not covered at all (then nothing is
-// known about it) — only such particles can have static neighbours.
-__device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9], bool* maybe_static = nullptr) {
-    // Cells on the rim of the u16 domain: the reference computes the box corners as u16 `pos.x - 1` / `pos.x + 1`
-    // (neighborhood_search.rs:193-194), which wrap in a release build (a debug build panics): the x- or y-range of the box is then
-    // empty and the particle gets NO neighbours, dynamic or static.  grid_min = -100 keeps real scenes 5000 cells away from the
-    // rim; the rule is restated for parity (tests/test_gpu_random_scenes.py puts a sheet of fluid into the corner).
-    const bool rim = cx - 1u >= 65534u || cy - 1u >= 65534u;
+// Round 4: the look-ups go through the NbGrid form of the directory (sphx_internal.hpp), in which no entry is special: a block that
+// is not covered points at the all-empty null block behind the table, block coordinates outside the directory's rectangle are
+// clamped into it (what is found there lies >= 60 cells away and fails the distance test; it never aliases a cell of the box
+// itself).  No "covered?" select on the directory index, on the entry, on the slot or on the range: 7 vector instructions per
+// cell of the box less than the round-3 form (slots9 / ranges9 over GridView).  Cells of the null block sort behind (or between)
+// real ones; they are empty, so their place in the order does not matter.
+// centre: the directory entry of the box's own block (its DIRN_FLAG); flags: the OR of all nine entries.
+__device__ __forceinline__ void slots9n(const NbGrid& g, uint32_t cx, uint32_t cy, uint32_t (&slot)[9], uint32_t& centre, uint32_t& flags) {
     // Low 6 bits of x-1, x, x+1 spread to the even bit positions (y: odd).  Spread once; the neighbours follow by dilated
     // decrement / increment, which wrap 0 <-> 63 like the cell coordinate does at a block edge.
     uint32_t lx[3], ly[3], bx[3], row[3];
-    bool vx[3], vy[3];
     lx[1] = spread6(cx);
     lx[0] = (lx[1] - 1u) & 0x555u;
     lx[2] = ((lx[1] | ~0x555u) + 1u) & 0x555u;
@@ -995,57 +1031,44 @@ __device__ __forceinline__ bool slots9(const GridView& g, uint32_t cx, uint32_t 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const uint32_t x = cx + (uint32_t)(d - 1), y = cy + (uint32_t)(d - 1);
-        bx[d] = (x >> BLOCK_SHIFT) - g.bx0;
-        const uint32_t by = (y >> BLOCK_SHIFT) - g.by0;
-        vx[d] = !rim && bx[d] < g.nbx;
-        vy[d] = by < g.nby;
-        row[d] = __umul24(by, g.nbx);  // both < 2^10 when the entry is used
+        bx[d] = min((x >> BLOCK_SHIFT) - g.bx0, g.nbx1);  // (a coordinate below the rectangle wraps to a huge value: clamped too)
+        row[d] = __umul24(min((y >> BLOCK_SHIFT) - g.by0, g.nby1), g.nbx);
     }
-    bool any = false;
-    uint32_t hint = 0;
-    // every load unconditional (entry 0 for boxes that leave the directory; the directory always has one readable entry): nine
-    // loads in flight together instead of nine branches
+    flags = 0;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const bool ok = vx[dx] && vy[dy];
-            uint32_t off = gat(g.dir, ok ? row[dy] + bx[dx] : 0u);
-            off = ok ? off : EMPTY;
-            any |= off != EMPTY;
-            hint |= off;  // EMPTY has every bit set
-            slot[dy * 3 + dx] = off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (ly[dy] | lx[dx]);
+            const uint32_t off = gat(g.dirn, row[dy] + bx[dx]);  // nine loads in flight together
+            flags |= off;
+            if (dx == 1 && dy == 1) centre = off;
+            slot[dy * 3 + dx] = (off & ~DIRN_FLAG) | (ly[dy] | lx[dx]);  // offsets are multiples of 4096
         }
-    if (maybe_static) *maybe_static = (hint & DIR_STATIC) != 0;
     sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
-    return any;
 }
-__device__ __forceinline__ void ranges9(const GridView& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
+__device__ __forceinline__ void ranges9n(const NbGrid& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const bool ok = slot[t] != EMPTY;
-        const uint2 se = gat(g.fine, ok ? slot[t] : 0u);  // unconditional: the table always has one readable entry
-        s[t] = ok ? se.x : 0u;
-        e[t] = ok ? se.y : 0u;
+        const uint2 se = gat(g.fine, slot[t]);
+        s[t] = se.x;
+        e[t] = se.y;
     }
 }
 
 // 8 waves per SIMD = 8 workgroups per CU: the staged rows (13 KiB) + the window (6 KiB) keep a workgroup below 20 KiB of the CU's
 // 160 KiB, and the kernel fits the register budget of 64.  At 1 M particles the 3 906 workgroups then fit into two "rounds" of the
 // chip.
-// The kernel is bound by the LENGTH of its chain of dependent memory round trips (each 1.5-3 us with every CU loading), not by
-// bytes or instructions (in-kernel stamps, profiles/r02_*): the chain is kept short —
-//   own position + window + directory + cell ranges are requested before the one barrier of the kernel;
-//   the candidate scan handles four candidates per trip, the density/alpha pass four neighbours per trip (out-of-window records
-//   are re-read from global memory in one batch per trip instead of one dependent load per candidate);
-//   the list format is decided per WAVEFRONT (no second barrier), the statistics are added per wavefront (no third one).
+// Round 1-2: the kernel was bound by the LENGTH of its chain of dependent memory round trips — own position + window + directory +
+// cell ranges are requested before the one barrier of the kernel; the candidate scan handles four candidates per trip; the list
+// format is decided per WAVEFRONT (no second barrier), the statistics are added per wavefront (no third one).  Since round 3 it is
+// bound by the number of VECTOR INSTRUCTIONS a wavefront issues (a wave64 instruction occupies its SIMD for four cycles): round 4
+// took 1 452 -> see DESIGN.md section 4 for where they went.
 #ifndef NB_BOUNDS
 #define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-// Everything behind the candidate scan of a neighbour build, shared by its two forms (k_neighbor_build: every particle walks
-// its own nine cell ranges; k_neighbor_build2: the particles of a cell share one candidate list): static neighbours, densities and
-// alpha factors, list format and rows, statistics.  On entry tile[w][k][lane] (k < min(ct, STAGE_ROWS); further entries at their
-// 32-bit address in `list`) holds the accepted dynamic neighbours of the lane's particle as slots of the [N|B] arrays, ascending.
+// Everything behind the candidate scan of a neighbour build: static neighbours, densities and alpha factors, out-of-window table,
+// list rows, statistics.  On entry tile[w][k][lane] (k < min(ct, STAGE_ROWS); further entries at their 32-bit address in `list`)
+// holds the accepted dynamic neighbours of the lane's particle, ascending.
 // MODE 0: lists only; 1: + densities and alpha factors; 2: + the first compute_density_change of the divergence loop that follows
 // (when it starts without a warm start); 3: + that loop's warm start (when it starts with one) — DivArgs.
 struct DivArgs {
@@ -1061,24 +1084,38 @@ __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restri
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
 __device__ __forceinline__ void lds_store_u32(uint32_t addr, uint32_t v) { *(lds_u32*)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t addr) { return *(lds_cu32*)(uintptr_t)addr; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
 typedef __attribute__((address_space(3))) const f32x4_a8 lds_cf4a8;  // two consecutive float2 slots: one ds_read2_b64
 constexpr uint32_t WIN_SLOTS = 256 + 2 * WIN_HALO;
 constexpr uint32_t WIN_PAD = 4;  // a trip of the candidate scan reads four consecutive slots from a clamped base: pad slots behind the window
 constexpr uint32_t ROW_B = 256;  // bytes between two rows of a wavefront's staged list
+// The window of positions the build stages IS the window the traversal kernels stage (NbHead): a staged entry that lies inside it is
+// its own narrow list entry (E >> 3), one outside it needs a line of the out-of-window table — the same test the density pass makes
+// to decide whether the neighbour's record is in LDS.
+static_assert(WIN_HALO == LIST_HALO && WIN_SLOTS == LIST_WIN && STAGE_ROWS % 4 == 0 && STAGE_ROWS % 3 == 0, "one window for the build and the lists");
 
 // A STAGED list entry (rows 0..STAGE_ROWS-1 of a wavefront, in LDS) is the neighbour's BYTE offset into the position window,
 // E = 8 (g - w0) for slot g of the [N|B] arrays ("negative" below the window; |E| < 2^31 since contexts hold < 2^28 slots): what
 // the candidate scan has in a register anyway, and what phase 2 addresses the window with.  Entries past the staged rows sit in
-// global memory as plain slots g (their 32-bit address in `list`).
+// global memory as plain slots g (their 32-bit address in `list`).  Phase 2 replaces an out-of-window entry by its narrow CODE
+// ((LIST_WIN + wave * WAVE_REMOTE + line) << 3 | 1: bit 0 marks it — offsets are multiples of eight) once it has given it a line of
+// the out-of-window table.
 __device__ __forceinline__ uint32_t entry_slot(uint32_t E, uint32_t w0) { return w0 + (uint32_t)((int32_t)E >> 3); }
+// three staged entries -> one word of a narrow row (pack3 of their E >> 3; what v2 carries above its ten bits lands in bits 30-31)
+__device__ __forceinline__ uint32_t pack3_staged(uint32_t v0, uint32_t v1, uint32_t v2) {
+    constexpr uint32_t M1 = ENTRY_MASK << ENTRY_BITS;
+    uint32_t t = v2 << (2u * ENTRY_BITS - 3u);
+    t = (t & ~M1) | ((v1 << (ENTRY_BITS - 3u)) & M1);
+    return (t & ~ENTRY_MASK) | ((v0 >> 3) & ENTRY_MASK);
+}
 
 template <int MODE>
-__device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const GridView& gs,
+__device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const NbGrid& gs,
                                         uint32_t* __restrict__ list, uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote,
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
-                                        uint32_t w0, uint32_t wlen, bool live, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
+                                        uint32_t w0, uint32_t wlen, bool live, bool scan, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
                                         uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
                                         const float* swin, float warm_i) {
     constexpr bool FUSE = MODE >= 1;
@@ -1088,94 +1125,135 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     uint32_t* const mytile = &tile[w][0][lane];
     const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
     uint32_t cd = 0;
-    uint32_t slot[9], s[9], e[9];
-    if (live) {
+    if (scan) {
         uint32_t flags = 0;
         ct = min(ct, MAX_NEIGHBORS);
         cd = ct;
         // static neighbours: only waves in which some lane's 3x3 box touches a block of the boundary's directory enter this section
-        // (the dynamic directory's DIR_STATIC bits say so without touching the boundary's directory: most waves skip even that)
+        // (the dynamic directory's DIRN_FLAG bits say so without touching the boundary's directory: most waves skip even that)
         // (cx, cy pass through an opaque asm so that the compiler recomputes the nine local offsets here instead of keeping them alive
         // — spilled — across the whole candidate section for a block that most waves never enter)
         // A static neighbour's slot in the [N|B] record arrays is soff + j.
         uint32_t cxs = cx, cys = cy;
         asm volatile("" : "+v"(cxs), "+v"(cys));
-        if (__any(maybe_static) && __any(slots9(gs, cxs, cys, slot))) {
-        ranges9(gs, slot, s, e);
+        if (__any(maybe_static)) {
+            uint32_t slot[9], s[9], e[9], centre, any9;
+            slots9n(gs, cxs, cys, slot, centre, any9);
+            if (__any((any9 & DIRN_FLAG) != 0u)) {
+                ranges9n(gs, slot, s, e);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            for (uint32_t j = s[t]; j < e[t]; ++j) {
-                const float2 pj = gat(posA, soff + j);
-                const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-                const float d2 = dx * dx + dy * dy;
-                if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
-                    if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
-                    if (ct < MAX_NEIGHBORS) {
-                        if (ct < STAGE_ROWS)
-                            mytile[ct * 64] = (soff + j - w0) * 8u;
-                        else
-                            list[ell_index(i, ct)] = soff + j;
-                        ct += 1;
+                for (int t = 0; t < 9; ++t) {
+                    for (uint32_t j = s[t]; j < e[t]; ++j) {
+                        const float2 pj = gat(posA, soff + j);
+                        const float dx = pj.x - pi.x, dy = pj.y - pi.y;
+                        const float d2 = dx * dx + dy * dy;
+                        if (d2 <= K.radius_sq && d2 > 1.0e-10f) {
+                            if (cd == MAX_NEIGHBORS) flags |= DF_NB_PANIC;  // neighborhood_search.rs:373 would panic
+                            if (ct < MAX_NEIGHBORS) {
+                                if (ct < STAGE_ROWS)
+                                    mytile[ct * 64] = (soff + j - w0) * 8u;
+                                else
+                                    list[ell_index(i, ct)] = soff + j;
+                                ct += 1;
+                            }
+                        }
                     }
                 }
             }
         }
-        }
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
     }
-    float div_err = 0.0f;
+    // ---- wave-uniform facts (scalar registers from here on) -------------------------------------------------------------------
+    const uint32_t mct = wave_max_u32(ct);     // the wavefront's longest list
+    const uint32_t m = min(mct, STAGE_ROWS);   // ... of it staged in LDS
+    const bool spill = mct > STAGE_ROWS;
+    // list format (NbHead), decided per wavefront.  A list entry names the neighbour's slot g in the [N|B] record arrays.  The
+    // traversal kernels stage the records of the slots [w0, w0 + wlen) in LDS; an entry inside that window is stored as its window
+    // slot g - w0, any other one (a neighbour far away in Morton order, or a boundary particle) gets the next free line r of this
+    // wavefront's quarter of the workgroup's out-of-window table and is stored as LIST_WIN + w * WAVE_REMOTE + r.  Lines are handed
+    // out in a fixed order (row, lane).  A wavefront with more than remote_cap / 4 such entries keeps 32-bit global slots (wide; its
+    // traversals gather from global memory).
+    // Narrow layout of a wave's slice: entries 6q .. 6q+5 of a lane are one 8-byte word at q * 512 + lane * 8, so a traversal
+    // fetches the first twelve entries of its particle with two coalesced loads that depend on nothing.
+    const uint32_t cap = K.remote_cap / 4u;
+    const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
+    // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
+    uint32_t* const rtab = remote + ((size_t)xcd_bid() * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
+    char* const slice = (char*)(list + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
+    const uint32_t t_row0 = lds_addr(mytile);
+    uint32_t run = 0;  // out-of-window entries of the staged rows so far (scalar)
+    // ---- phase 2: ONE walk over the accepted list does three things ------------------------------------------------------------------
+    //  * densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) (+ MODE 2 / 3 sums), in list order: the entries
+    //    of a trip (four) and their records are read together, the accumulation stays sequential; the trip ends after two when no
+    //    lane of the wavefront has a third (x and y components ride in packed instructions — v_pk_add_f32 / v_pk_mul_f32: plain IEEE
+    //    operations on both halves, the same roundings as the scalar forms);
+    //  * an entry outside the window has its record re-read from global memory — and, round 4, gets its line of the out-of-window
+    //    table on the spot (ballot + mbcnt, only in trips that hold such an entry; round 3 ran a separate format pass over all rows:
+    //    twelve instructions per row for what is needed by every twentieth entry);
+    //  * what is left of the format pass is a pack of the staged rows (pack3_staged, below).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
+    float gss = 0.0f;
+    f32x2 gs2 = {0.0f, 0.0f};
+    float delta = 0.0f;  // DIV: sum of (v_i - v_j) . grad W_ij, dfsph.rs:249-280, in the order k_compute_error<true> adds it
+    f32x2 ws = {0.0f, 0.0f};                        // WARM: sum of (k_i + k_j) grad W_ij, dfsph.rs:316-344, as k_correct<true, false> adds it
+    const float ki = 0.5f * fmaxf(warm_i, dv.lim);  // dfsph.rs:356-358
+    const f32x2 pi2 = {pi.x, pi.y}, vi2 = {vi.x, vi.y}, mass2 = {K.mass, K.mass};
 #ifdef SPHX_ABL_NOPHASE2
-    if (false) {
+    for (uint32_t k0 = 0; false;) {
 #else
-    if (FUSE && live) {
+    for (uint32_t k0 = 0; k0 < mct; k0 += 4) {
 #endif
-        // phase 2: densities (fluidparticleworld.rs:197-231) and alpha factors (dfsph.rs:68-97) over the accepted list, in list order.
-        // The entries of a trip (four) and their records are read together, the accumulation stays sequential; the trip ends after two
-        // when no lane of the wavefront has a third (a wavefront whose longest list has 9 or 10 entries does 10 slots of arithmetic)
-        // (x and y components ride in packed instructions — v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations on both halves, the
-        // same roundings as the scalar forms)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        float rho = wendland_eval(K, 0.0f) * K.mass;  // self contribution, fluidparticleworld.rs:213
-        float gss = 0.0f;
-        f32x2 gs = {0.0f, 0.0f};
-        float delta = 0.0f;  // DIV: sum of (v_i - v_j) . grad W_ij, dfsph.rs:249-280, in the order k_compute_error<true> adds it
-        f32x2 ws = {0.0f, 0.0f};                        // WARM: sum of (k_i + k_j) grad W_ij, dfsph.rs:316-344, as k_correct<true, false> adds it
-        const float ki = 0.5f * fmaxf(warm_i, dv.lim);  // dfsph.rs:356-358
-        const f32x2 pi2 = {pi.x, pi.y}, vi2 = {vi.x, vi.y}, mass2 = {K.mass, K.mass};
-        for (uint32_t k0 = 0; k0 < ct; k0 += 4) {
-            uint32_t E[4];  // window byte offsets (see entry_slot)
-            float2 rj[4];
-            float2 vj[4];
-            float wj4[4];
+        uint32_t E[4];  // window byte offsets (see entry_slot)
+        float2 rj[4];
+        float2 vj[4];
+        float wj4[4];
+        const bool staged = k0 < STAGE_ROWS;  // (scalar; STAGE_ROWS is a multiple of four: a trip is staged or spilled as a whole)
+        const uint32_t ta = t_row0 + k0 * ROW_B;
+        if (staged) {
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) E[u] = lds_read_u32(&tile[w][min(k0 + u, STAGE_ROWS - 1u)][lane]);
-            if (k0 + 4u > STAGE_ROWS) {
+            for (uint32_t u = 0; u < 4; ++u) E[u] = lds_load_u32(ta + u * ROW_B);
+        } else {
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u)
-                    if (k0 + u >= STAGE_ROWS && k0 + u < ct) E[u] = (list[ell_index(i, k0 + u)] - w0) * 8u;
-            }
-            bool far = false;
+            for (uint32_t u = 0; u < 4; ++u) E[u] = k0 + u < ct ? (list[ell_index(i, k0 + u)] - w0) * 8u : 0u;
+        }
+        bool on[4], far[4];
+        unsigned long long fm[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+        for (uint32_t u = 0; u < 4; ++u) {
+            on[u] = k0 + u < ct;
+            far[u] = on[u] && E[u] >= wlen_b;  // static neighbours (soff + boundary index) are never in the window
+            fm[u] = __builtin_amdgcn_ballot_w64(far[u]);
+            if (FUSE) {
                 const uint32_t wb = min(E[u], wlen_b);  // slot wlen: pad
                 rj[u] = lds_read_f2((const float2*)((const char*)win + wb));
                 if (DIV) vj[u] = lds_read_f2((const float2*)((const char*)vwin + wb));
                 if (WARM) wj4[u] = lds_read_f1((const float*)((const char*)swin + (wb >> 1)));
-                far |= k0 + u < ct && E[u] >= wlen_b;
             }
-            if (far) {  // static neighbours (soff + boundary index) are never in the window
+        }
+        if ((fm[0] | fm[1] | fm[2] | fm[3]) != 0ull) {  // (scalar branch)
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u)
-                    if (k0 + u < ct && E[u] >= wlen_b) {
-                        const uint32_t gb = w0b + E[u];  // 8 g
-                        rj[u] = *(const float2*)((const char*)posA + gb);
-                        if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
-                        if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (fm[u] == 0ull) continue;  // (scalar)
+                const uint32_t gb = w0b + E[u];  // 8 g
+                if (FUSE && far[u]) {
+                    rj[u] = *(const float2*)((const char*)posA + gb);
+                    if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
+                    if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
+                }
+                if (cap != 0u && staged) {
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm[u], run));
+                    run += (uint32_t)__popcll(fm[u]);
+                    if (far[u] && r < WAVE_REMOTE) {
+                        rtab[r] = gb >> 3;
+                        lds_store_u32(ta + u * ROW_B, ((rbase + r) << 3) | 1u);
                     }
+                }
             }
+        }
+        if (FUSE) {
             auto add = [&](uint32_t u) {
-                const bool on = k0 + u < ct;
                 const f32x2 d = f32x2{rj[u].x, rj[u].y} - pi2;  // ri_to_rj
                 const f32x2 dd = d * d;
                 const float r = sqrt_dist(dd.x + dd.y);
@@ -1187,32 +1265,36 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 const f32x2 sgd = f32x2{sg, sg} * d;  // wendland_grad(ri, rj)
                 const f32x2 g = sgd * mass2;
                 const f32x2 gg = g * g;
-                const f32x2 t_gs = gs + g;
+                const f32x2 t_gs = gs2 + g;
                 const float t_gss = gss + (gg.x + gg.y);
-                rho = on ? t_rho : rho;
-                gs.x = on ? t_gs.x : gs.x;
-                gs.y = on ? t_gs.y : gs.y;
-                gss = on ? t_gss : gss;
+                rho = on[u] ? t_rho : rho;
+                gs2.x = on[u] ? t_gs.x : gs2.x;
+                gs2.y = on[u] ? t_gs.y : gs2.y;
+                gss = on[u] ? t_gss : gss;
                 if (DIV) {  // the operations of k_compute_error<true>
                     const f32x2 dvg = (vi2 - f32x2{vj[u].x, vj[u].y}) * sgd;
                     const float t_delta = delta + (dvg.x + dvg.y);
-                    delta = on ? t_delta : delta;
+                    delta = on[u] ? t_delta : delta;
                 }
                 if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
                     const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
                     const float sk = k0 + u < cd ? ki + kj : ki;
                     const f32x2 t_ws = ws + f32x2{sk, sk} * sgd;
-                    ws.x = on ? t_ws.x : ws.x;
-                    ws.y = on ? t_ws.y : ws.y;
+                    ws.x = on[u] ? t_ws.x : ws.x;
+                    ws.y = on[u] ? t_ws.y : ws.y;
                 }
             };
             add(0);
             add(1);
-            if (!__any(ct > k0 + 2u)) break;
-            add(2);
-            add(3);
+            if (mct > k0 + 2u) {  // (scalar)
+                add(2);
+                add(3);
+            }
         }
-        const float gsx = gs.x, gsy = gs.y, wsx = ws.x, wsy = ws.y;
+    }
+    float div_err = 0.0f;
+    if (FUSE && live) {
+        const float gsx = gs2.x, gsy = gs2.y, wsx = ws.x, wsy = ws.y;
         density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
         const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
         alpha[i] = alpha_i;
@@ -1223,55 +1305,10 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         }
         if (WARM) dv.velw[i] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
     }
-    // ---- list format (NbHead), decided per wavefront ------------------------------------------------------------------------------
-    // A list entry names the neighbour's slot g in the [N|B] record arrays.  The traversal kernels stage the records of the slots
-    // [lw0, lw0 + lwlen) in LDS; an entry inside that window is stored as its window slot g - lw0, any other one (a neighbour far
-    // away in Morton order, or a boundary particle) gets the next free line r of this wavefront's quarter of the workgroup's
-    // out-of-window table and is stored as LIST_WIN + w * WAVE_REMOTE + r.  Lines are handed out in a fixed order (row, lane).  A
-    // wavefront with more than remote_cap / 4 such entries keeps 32-bit global slots (wide; its traversals gather from global memory).
-    // 16-bit layout of a wave's slice: entries 4q .. 4q+3 of a lane are one 8-byte word at q * 512 + lane * 8, so a traversal
-    // fetches the first twelve entries of its particle with three coalesced loads that depend on nothing.
-    const uint32_t lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
-    const uint32_t lwlen = min(b0 + 256u + LIST_HALO, n) - lw0;
-    const uint32_t wshift = w0 - lw0;  // staged entry -> slot of the list window: (E >> 3) + (w0 - lw0)
-    const uint32_t cap = K.remote_cap / 4u;
-    uint32_t m = min(ct, STAGE_ROWS);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-#ifdef SPHX_ABL_NOFORMAT  // (instruction-count experiments: tools/ab_build.sh)
-    m = 0;
-#endif
-    const bool spill = __any(ct > STAGE_ROWS);
-    // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
-    uint32_t* const rtab = remote + ((size_t)xcd_bid() * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
-    char* const slice = (char*)(list + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
-    // optimistic single pass: 16-bit rows and table lines go out while the lines are counted; a wavefront that overflows its quarter
-    // of the table (rare) rewrites its rows as 32-bit ones afterwards
-    uint32_t run = 0;
-    if (cap) {
-        // three rows per trip = one 32-bit word per lane, half of the 8-byte word the lane owns in a row group (rows >= m of the last
-        // word hold don't-care values: traversals stop at the count)
-        const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
-        const uint32_t lane8 = lane * 8u;
-        const uint32_t* const trow = &tile[w][0][lane];
-        for (uint32_t k0 = 0; k0 < m; k0 += 3u) {
-            uint32_t sl[3];
-#pragma unroll
-            for (uint32_t u = 0; u < 3; ++u) {
-                const uint32_t gl = (uint32_t)((int32_t)lds_read_u32(trow + (k0 + u) * 64u) >> 3) + wshift;  // g - lw0
-                const bool rem = k0 + u < ct && gl >= lwlen;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(rem);
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, run));
-                run += (uint32_t)__popcll(mask);
-                if (rem && r < WAVE_REMOTE) rtab[r] = gl + lw0;
-                sl[u] = rem ? rbase + r : gl;
-            }
-            *(uint32_t*)(slice + ((k0 / GROUP) * 512u + ((k0 / 3u) & 1u) * 4u + lane8)) = pack3(sl[0], sl[1], sl[2]);
-        }
-    }
+    // ---- list rows ----------------------------------------------------------------------------------------------------------------
     uint32_t spill_rem = 0, spill_before = 0;
     if (spill) {
-        for (uint32_t k = STAGE_ROWS; k < ct; ++k) spill_rem += (list[ell_index(i, k)] - lw0 >= lwlen) ? 1u : 0u;
+        for (uint32_t k = STAGE_ROWS; k < ct; ++k) spill_rem += (list[ell_index(i, k)] - w0 >= wlen) ? 1u : 0u;
         const uint32_t inc = wave_incl_scan(spill_rem);
         spill_before = inc - spill_rem;
         spill_rem = (uint32_t)__shfl((int)inc, 63, 64);
@@ -1281,42 +1318,54 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (live) counts[i] = (uint16_t)(cd | (ct << 7));  // NeighborRange, neighborhood_search.rs:269-273
     if (lane == 0) wave[i >> 6] = (wide ? 0x80000000u : rtot);  // the wavefront's list format + table lines in use
     if (wide) {
-        // entries past the staged rows already sit at their 32-bit address
+        // 32-bit rows; entries past the staged rows already sit at their 32-bit address.  An entry that phase 2 has turned into a code
+        // finds its slot in the table line it was given (written by this very lane).
         const size_t row0 = (size_t)(i >> 6) * 64;
-        for (uint32_t k = 0; k < m; ++k) list[(row0 + k) * 64 + lane] = entry_slot(lds_read_u32(&tile[w][k][lane]), w0);
-    } else if (spill) {
-        // Entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address: row k at byte
-        // 256 k + 4 lane of the slice).  Their narrow home — the 8-byte word of group q = k / 6 at byte 512 q + 8 lane — lies below
-        // every wide row >= 6 q (q >= 2 here), and the whole wavefront reads the six wide rows of a group before it writes the group's
-        // word: rewriting in ascending q never overwrites an entry still to be read.
-        uint32_t r = run + spill_before;
-        uint32_t ctmax = ct;
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t v = lds_load_u32(t_row0 + k * ROW_B);
+            uint32_t g = entry_slot(v, w0);
+            if ((v & 1u) && k < ct) g = __hip_atomic_load(&rtab[(v >> 3) - rbase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            list[(row0 + k) * 64 + lane] = g;
+        }
+    } else {
+        // three rows = one 32-bit word per lane, half of the 8-byte word the lane owns in a row group (rows >= m of the last word hold
+        // don't-care values: traversals stop at the count)
+        const uint32_t lane8 = lane * 8u;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ctmax = max(ctmax, (uint32_t)__shfl_xor((int)ctmax, d, 64));
-        for (uint32_t k0 = STAGE_ROWS; k0 < ctmax; k0 += GROUP) {
-            uint32_t sl[GROUP];
+        for (uint32_t k0 = 0; k0 < STAGE_ROWS; k0 += 3u) {
+            if (k0 >= m) break;  // (scalar)
+            const uint32_t v0 = lds_load_u32(t_row0 + k0 * ROW_B), v1 = lds_load_u32(t_row0 + (k0 + 1u) * ROW_B), v2 = lds_load_u32(t_row0 + (k0 + 2u) * ROW_B);
+            *(uint32_t*)(slice + ((k0 / GROUP) * 512u + ((k0 / 3u) & 1u) * 4u + lane8)) = pack3_staged(v0, v1, v2);
+        }
+        if (spill) {
+            // Entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address: row k at byte
+            // 256 k + 4 lane of the slice).  Their narrow home — the 8-byte word of group q = k / 6 at byte 512 q + 8 lane — lies below
+            // every wide row >= 6 q (q >= 2 here), and the whole wavefront reads the six wide rows of a group before it writes the group's
+            // word: rewriting in ascending q never overwrites an entry still to be read.
+            uint32_t r = run + spill_before;
+            for (uint32_t k0 = STAGE_ROWS; k0 < mct; k0 += GROUP) {
+                uint32_t sl[GROUP];
 #pragma unroll
-            for (uint32_t u = 0; u < GROUP; ++u) {
-                const bool on = k0 + u < ct;
-                const uint32_t g = on ? list[ell_index(i, k0 + u)] : lw0;
-                const bool rem = on && g - lw0 >= lwlen;
-                if (rem) rtab[r] = g;
-                sl[u] = rem ? LIST_WIN + w * WAVE_REMOTE + r : g - lw0;
-                r += rem ? 1u : 0u;
+                for (uint32_t u = 0; u < GROUP; ++u) {
+                    const bool on = k0 + u < ct;
+                    const uint32_t g = on ? list[ell_index(i, k0 + u)] : w0;
+                    const bool rem = on && g - w0 >= wlen;
+                    if (rem) rtab[r] = g;
+                    sl[u] = rem ? rbase + r : g - w0;
+                    r += rem ? 1u : 0u;
+                }
+                // (all lanes of the wavefront have read this group's wide rows by now: the loads above are complete before the store issues
+                // only per lane, so make it so for the wavefront)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (k0 < ct) *(uint2*)(slice + ((k0 / GROUP) * 512u + lane * 8u)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
             }
-            // (all lanes of the wavefront have read this group's wide rows by now: the loads above are complete before the store issues
-            // only per lane, so make it so for the wavefront)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (k0 < ct) *(uint2*)(slice + ((k0 / GROUP) * 512u + lane * 8u)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
         }
     }
     // total number of list entries and of out-of-window entries (stats only): one pair of striped atomics per wavefront
-    unsigned long long tot = ct;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_down(tot, d, 64);
+    const uint32_t tot = wave_sum_u32(ct);
     if (lane == 0) {
-        if (tot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, tot);
+        if (tot) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].nb_entries, (unsigned long long)tot);
         if (rtot && !wide) atomicAdd(&scal->stripe[blockIdx.x % STRIPES].rem_entries, (unsigned long long)rtot);
     }
     // DIV: this launch stands in for the divergence loop's first compute_density_change — its residual goes where that kernel's goes
@@ -1333,7 +1382,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 #endif
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8, MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8))) void k_neighbor_build(
-    const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, GridView gd, GridView gs, uint32_t* __restrict__ list,
+    const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, NbGrid gd, NbGrid gs, uint32_t* __restrict__ list,
     uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
@@ -1382,10 +1431,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     }
     uint32_t cx, cy;
     cell_of(K, pi, cx, cy);
-    uint32_t slot[9], s[9], e[9];
-    bool maybe_static;
-    slots9(gd, cx, cy, slot, &maybe_static);
-    ranges9(gd, slot, s, e);
+    // Cells on the rim of the u16 domain: the reference computes the box corners as u16 `pos.x - 1` / `pos.x + 1`
+    // (neighborhood_search.rs:193-194), which wrap in a release build (a debug build panics): the x- or y-range of the box is then
+    // empty and the particle gets NO neighbours, dynamic or static.  grid_min = -100 keeps real scenes 5000 cells away from the
+    // rim; the rule is restated for parity (tests/test_gpu_random_scenes.py puts a sheet of fluid into the corner).
+    const bool scan = live && !(cx - 1u >= 65534u || cy - 1u >= 65534u);
+    uint32_t slot[9], s[9], e[9], centre, any9;
+    slots9n(gd, cx, cy, slot, centre, any9);
+    // only a particle whose block has the boundary's directory in its 3x3 blocks can have static neighbours; a particle whose own
+    // block lies outside the directory's rectangle (a stray: its centre look-up was clamped) is given the benefit of the doubt
+    const bool maybe_static = (centre & DIRN_FLAG) != 0u || (cx >> BLOCK_SHIFT) - gd.bx0 > gd.nbx1 || (cy >> BLOCK_SHIFT) - gd.by0 > gd.nby1;
+    ranges9n(gd, slot, s, e);
 #pragma unroll
     for (uint32_t u = 0; u < NWIN; ++u)
         if (threadIdx.x + u * 256u < wlen) {
@@ -1399,7 +1455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     SPHX_STAMP(0)
     uint32_t ct = 0;
     const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
-    if (live) {
+    if (scan) {
         // phase 1: filter
         SPHX_STAMP(1)
 #ifndef SPHX_ABL_NOLOOP
@@ -1410,6 +1466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const uint32_t t_dump = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;
         uint32_t ta = t_base;
         const uint32_t far_lim = wlen_b > 24u ? wlen_b - 24u : 0u;  // a trip starting at or beyond this byte offset (or below the window) leaves the window
+        const uint32_t nw0b = 0u - w0b;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
@@ -1420,14 +1477,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             //   is also what is stored for an accepted candidate (entry_slot);
             // * a candidate outside the window is re-read from global memory — one branch per trip, its loads in flight together;
             // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
-            const uint32_t eb = e[t] * 8u - w0b;
-            uint32_t ab = s[t] * 8u - w0b;
+            const uint32_t eb = (e[t] << 3) + nw0b;  // (one shift-add each)
+            uint32_t ab = (s[t] << 3) + nw0b;
             while (ab != eb) {
                 const uint32_t rem = eb - ab;  // bytes of candidates left in this cell (>= 8)
                 const char* const base = (const char*)win + min(ab, wlen_b);  // below or beyond the window: the pad slots
                 const f32x4 p01 = *(lds_cf4a8*)base, p23 = *(lds_cf4a8*)(base + 16);
                 float2 pj[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
-#ifndef SPHX_ABL_NOFALLBACK  // (timing experiments: tools/ab_build.sh)
                 if (ab >= far_lim) {
                     // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL four from
                     // global memory (one address, four loads with immediate offsets; what the window holds is the same data, and the
@@ -1436,7 +1492,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) pj[u] = gp[u];
                 }
-#endif
                 bool acc[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
@@ -1475,7 +1530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, scan, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
     SPHX_STAMP(7)
 }
 
@@ -1823,9 +1878,7 @@ __device__ __forceinline__ unsigned long long residual_fixed(float e, bool& bad)
 }
 __device__ __forceinline__ void block_residual_add(float e, DevScalars* __restrict__ scal) {
     bool bad;
-    unsigned long long f = residual_fixed(e, bad);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) f += __shfl_down(f, d, 64);
+    const unsigned long long f = wave_sum_u63(residual_fixed(e, bad));  // (terms < 2^54; the total is wave-uniform)
     __shared__ unsigned long long ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = f;
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&scal->flags, DF_NONFINITE);
