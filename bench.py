@@ -27,6 +27,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): the practical ceiling of a streaming kernel
+SIMDS = 256 * 4              # 256 CUs x 4 SIMDs (same guide); a wave64 vector instruction occupies its SIMD for 4 cycles
+ENGINE_CLOCK_HZ = 2.4e9      # peak engine clock
 
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
@@ -187,6 +189,10 @@ def launch_ranks(args, argv):
 
 
 def main():
+    # dmabuf IPC (RCCL / device-buffer sharing across processes needs it on this pool): must be in the environment before anything
+    # loads the HIP runtime — also when an external launcher (the driver's `python -m torch.distributed.run ... bench.py`) started us
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t_process_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -194,10 +200,10 @@ def main():
     ap.add_argument("--skip-steps", type=int, default=0,
                     help="untimed steps before the warm-up (SURVEY 8(d): a second window after 2000 steps = the violent phase, high Id/Iv)")
     ap.add_argument("--particles", type=int, default=None,
-                    help="target fluid particles per GPU; default: 1 M on one GPU (BASELINE configs[1]), 16 M per GPU on several (4 GPUs = configs[3], "
-                         "64 M on 2x2 tiles; 8 GPUs = configs[4], 128 M on 8 strips)")
+                    help="target fluid particles per GPU; default: 16 M (one GPU = BASELINE configs[2], the largest single-GPU config, where the HBM "
+                         "roofline binds; 4 GPUs = configs[3], 64 M on 2x2 tiles; 8 GPUs = configs[4], 128 M on 8 strips)")
     ap.add_argument("--no-also", action="store_true", help="one GPU, default workload: skip the two further windows of the line's `also` list "
-                                                           "(16 M from t=0; 1 M after 3750 steps)")
+                                                           "(1 M from t=0 = BASELINE configs[1]; 1 M after 3750 steps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--halo", type=int, default=16, help="widest ghost halo in cells (multi-GPU); the band in use adapts to the ring budget")
     ap.add_argument("--fixed-halo", action="store_true", help="always exchange the full --halo band")
@@ -236,7 +242,7 @@ def main():
         sys.exit("bench.py: --gpus must be >= 1")
     default_workload = args.particles is None
     if args.particles is None:
-        args.particles = 1_000_000 if args.gpus == 1 else 16_000_000
+        args.particles = 16_000_000
     # the further windows ride on the plain `python bench.py [--steps K --warmup W]` run only (what the driver starts)
     args.also = (default_workload and not args.no_also and args.gpus == 1 and args.solver == "dfsph" and not args.skip_steps
                  and not any(args.fixed_iterations) and args.tolerance_scale == 1.0 and not args.force_tiles and not args.lists_32bit
@@ -270,18 +276,24 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        ipc_env = [os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")]
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             seen = torch.tensor([1.0], dtype=torch.float64)
             dist.all_reduce(seen)  # every rank arrived
             assert int(seen.item()) == world
+            gathered_env = [None] * world
+            dist.all_gather_object(gathered_env, ipc_env[0])  # what every rank's environment holds (set at the top of main())
+            ipc_env = gathered_env
         if rank == 0:
             os.write(result_fd, (json.dumps({"metric": "particle-steps/sec (whole node), 2D DFSPH dam-break", "value": None,
                                              "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                                              "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                                              "dtype": "f32", "data": "none (dry run of the rank launcher)",
                                              "config": {"workload": "dry run: no compute; would run " + dry_workload(args.particles, world),
-                                                        "particles_per_gpu": args.particles}}) + "\n").encode())
+                                                        "particles_per_gpu": args.particles,
+                                                        "HSA_ENABLE_IPC_MODE_LEGACY_per_rank": ipc_env,
+                                                        "launcher": "external (RANK was in the environment)" if launched else "bench.py's own child"}}) + "\n").encode())
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -358,6 +370,21 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         return traffic, src
+
+    def valu_of(name, n):
+        # vector instructions / issue cycles of a kernel per launch from the SQ counters of the committed rocprofv3 pass of this command
+        # (profiles/r0*_valu_*.json, tools/make_valu_json.py) when the workload matches, else None
+        import glob
+
+        rec = None
+        for vf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_valu_*.json"))):
+            try:
+                vj = json.load(open(vf))
+                if abs(vj["workload_particles"] - n) < 0.02 * n and name in vj["per_launch"]:
+                    rec = dict(vj["per_launch"][name], source=vj["source"] + f" [file {os.path.basename(vf)}" + (f", taken at git {vj['git_head']}]" if "git_head" in vj else "]"))
+            except (OSError, KeyError, ValueError):
+                pass
+        return rec
 
     def measure(one_step, k_steps, ctx, barrier, steps, warmup, skip_steps, want_roofline, n, reduce_max=None):
         """--skip-steps + --warmup untimed steps, then EXACTLY `steps` timed ones between two barriers.  Returns the timing, the step
@@ -444,6 +471,20 @@ def main():
                 "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (which keeps kernels from overlapping their "
                         "neighbours' tails): its sum exceeds ms_per_step; information only",
             }
+            if dominant.startswith("neighbor_build"):
+                # The neighbour build is bound by the vector instructions its wavefronts issue, not by its bytes: the
+                # HBM figures above stay (the contract's roofline), the binding resource is stated beside them.
+                roof["bound"] = "valu"
+                roof["bound_note"] = ("the dominant kernel is bound by vector-instruction issue (valu_issue_frac of every SIMD's cycles over the launch); "
+                                      "achieved / peak / frac are its algorithmic bytes against the HBM peak, as the bench contract prescribes")
+                vrec = valu_of(dominant, n)
+                if vrec and vrec.get("active_inst_valu"):
+                    roof["valu_issue_frac"] = vrec["active_inst_valu"] * 4.0 / (SIMDS * ENGINE_CLOCK_HZ * avg_ms * 1e-3)
+                    roof["valu"] = {"insts_valu_per_wavefront": vrec["insts_valu_per_wave"], "wavefronts": vrec["waves"],
+                                    "sq_active_inst_valu": vrec["active_inst_valu"], "simds": SIMDS, "engine_clock_hz": ENGINE_CLOCK_HZ,
+                                    "formula": "SQ_ACTIVE_INST_VALU * 4 cycles / (SIMDs * engine clock * avg_launch_ms)", "source": vrec["source"]}
+                else:
+                    roof["valu_issue_frac"] = None
         return elapsed, stats, roof
 
     def iteration_stats(stats):
@@ -476,7 +517,7 @@ def main():
                 "frac_of_hbm_peak_whole_step": bstep * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                 "frac_of_achievable_6300_whole_step": bstep * n * steps / elapsed / 1e9 / HBM_ACHIEVABLE_GBS,
                 "note": "at 1 M particles the working set (~170 MB) sits inside the 256 MB Infinity Cache: the HBM roofline is "
-                        "a soft bound there; 16 M (--particles 16000000) is the size where it binds"}
+                        "a soft bound there; 16 M (the default) is the size where it binds"}
 
     def single_window(particles, skip_steps, steps, warmup, want_roofline=True):
         """One measurement on ONE context: the dam-break scaled to `particles`, `skip_steps` untimed steps, warm-up, timed steps."""
@@ -550,15 +591,17 @@ def main():
             o["dominant_kernel"] = {k: r["roof"][k] for k in ("kernel", "avg_launch_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "traffic")}
         return o
 
-    config_name = {1: "BASELINE configs[1]", 4: "BASELINE configs[3] (64 M, 2x2 tiles)", 8: "BASELINE configs[4] (128 M, 8 strips)"}
+    config_name = {1: "BASELINE configs[1]", 2: "BASELINE configs[2] (16 M, the largest single-GPU config)", 4: "BASELINE configs[3] (64 M, 2x2 tiles)",
+                   8: "BASELINE configs[4] (128 M, 8 strips)"}
     multi = None
     if world == 1 and not args.force_tiles:
         head = single_window(args.particles, args.skip_steps, args.steps, args.warmup, want_roofline=not args.no_roofline)
         also = []
         if args.also:
-            # the windows the headline does not show: configs[2] — 16 M particles, where the HBM roofline binds — and
-            # the iterating regime of the reference scene (after 3 750 steps the divergence loop needs two iterations and a warm start)
-            also.append(window_summary(single_window(16_000_000, 0, 20, 2), "DFSPH 16 M particles from t=0 (BASELINE configs[2])"))
+            # the windows the headline (configs[2], 16 M: the largest single-GPU config) does not show: configs[1] — 1 M particles, resident
+            # in the Infinity Cache — and the iterating regime of the reference scene (after 3 750 steps the divergence loop needs two
+            # iterations and a warm start)
+            also.append(window_summary(single_window(1_000_000, 0, 100, 5), "DFSPH 1 M particles from t=0 (BASELINE configs[1])"))
             also.append(window_summary(single_window(1_000_000, 3750, 100, 5), "DFSPH 1 M particles after 3750 steps (iterating regime: Iv = 2 with warm start)"))
         n_global, n, scale = head["n"], head["n"], head["scale"]
         out = {
@@ -579,6 +622,7 @@ def main():
                 "workload": f"{args.solver.upper()} 2D dam-break (main.rs:177-196 scene x{scale:.2f}), {n_global} fluid + {head['n_boundary']} boundary particles "
                             f"on one GPU, adaptive CFL timer from t=0"
                             + (f" = {config_name[1]}" if (args.solver == "dfsph" and abs(n_global - 1_000_000) < 20_000 and not args.skip_steps) else "")
+                            + (f" = {config_name[2]}" if (args.solver == "dfsph" and abs(n_global - 16_000_000) < 300_000 and not args.skip_steps) else "")
                             + (f", window after {args.skip_steps} steps" if args.skip_steps else "")
                             + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
@@ -602,7 +646,9 @@ def main():
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and args.solver == "dfsph":
-            out["cpu_baseline"] = cpu_baseline(scale)
+            # a bounded sample of the same workload: the same dam-break at 1 M particles (the restatement's cost per particle-step does not
+            # depend on the size; 16 M would be ~7 s per step on this host)
+            out["cpu_baseline"] = cpu_baseline(min(scale, float(np.sqrt(1_000_000 / 4050.0))))
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         return
@@ -653,10 +699,31 @@ def main():
         if not use_builtin:
             comm = TorchCommOps(dist, torch.device("cuda", dev_index), shm_name=job + "t" if args.scalar_comm == "shm" else None)
             multi = MultiSolver.rank(params, dev_index, rank, world, comm=comm, **kw)
-    multi.set_boundary(boundary)
-    multi.upload(pos)
+    def diag(stage):
+        # what a maintainer needs when an N > 1 run dies (nobody has seen one on real links yet): printed on EVERY failure path
+        try:
+            rv = ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else "?"
+        except Exception as ex:  # noqa: BLE001
+            rv = f"unavailable ({ex})"
+        seen = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        tr = None
+        try:
+            tr = multi.info()["transport"] if multi is not None else None
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stderr.write(f"bench.py: rank {rank}/{world} failed in {stage}: backend={args.backend} comm={args.comm} transport={tr} world_size_seen={seen} "
+                         f"RCCL={rv} device={dev_index} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} "
+                         f"particles_per_gpu={args.particles} t+{time.perf_counter() - t_process_start:.1f}s\n")
+
+    try:
+        multi.set_boundary(boundary)
+        multi.upload(pos)
+    except Exception:
+        diag("scene upload")
+        raise
     ctx = multi.tile_context(0)
     n = n_global // world
+    setup_seconds = time.perf_counter() - t_process_start  # process start -> tiles resident (imports, rendezvous, scene build of the GLOBAL scene on every rank, upload)
 
     def one_step():
         st = multi.step(timer, diam)
@@ -679,7 +746,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, stats, roof = measure(one_step, k_steps, ctx, barrier, args.steps, args.warmup, args.skip_steps, not args.no_roofline, n, reduce_max)
+    try:
+        elapsed, stats, roof = measure(one_step, k_steps, ctx, barrier, args.steps, args.warmup, args.skip_steps, not args.no_roofline, n, reduce_max)
+    except Exception:
+        diag("the step loop")
+        raise
     it = iteration_stats(stats)
     minfo = multi.info()
     # measured list statistics of the tiles' latest neighbour build, summed over the ranks; per-rank owned counts
@@ -722,6 +793,7 @@ def main():
                 "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
                 "particles_total": n_global,
                 "transport": minfo["transport"],
+                "setup_seconds": setup_seconds,
                 "parallelism":
                 f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
                 f"particle-count quantiles), step loop inside libsphx (sphx_multi), ghost halo {minfo['halo_now']} of <= {args.halo} cells (follows "

@@ -44,6 +44,37 @@ def test_default_multi_gpu_workload_is_the_baseline_config(gpus, total, name):
     assert abs(n_total - total * 1_000_000) < 0.01 * total * 1_000_000, wl
 
 
+def test_single_gpu_default_workload_is_the_largest_single_gpu_config():
+    """`python bench.py` / `--gpus 1`: the headline is BASELINE configs[2], 16 M particles — the size where the HBM roofline binds
+    (VERDICT r03 item 3); the 1 M windows ride in `also`."""
+    rc, out, err = run(["--dry-run"])
+    assert rc == 0, err
+    d = json.loads([ln for ln in out.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["config"]["particles_per_gpu"] == 16_000_000
+    n_total = int(d["config"]["workload"].split("~")[1].split(" ")[0])
+    assert abs(n_total - 16_000_000) < 160_000
+
+
+def test_ranks_started_by_an_external_launcher_get_the_dmabuf_ipc_variable():
+    """The driver starts the N > 1 bench as `python -m torch.distributed.run ... bench.py --gpus N`: bench.py's own launcher (which sets
+    HSA_ENABLE_IPC_MODE_LEGACY=0 for its children) is not involved, so every rank must set it itself before anything loads the HIP
+    runtime."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), BENCH, "--gpus", "2", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["launcher"].startswith("external")
+    assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY_per_rank"] == ["0", "0"]
+
+
 def test_world_size_must_match_gpus():
     rc, out, err = run(["--gpus", "2", "--dry-run"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert rc != 0 and out.strip() == ""

@@ -32,18 +32,19 @@ def table(path):
     return out
 
 
-fetch, write = table(sys.argv[1]), table(sys.argv[2])
-res = {}
-for k, label in NAMES.items():
-    if k in fetch or k in write:
-        f, w = fetch.get(k, 0), write.get(k, 0)
-        res[label] = {"fetch": f, "write": w, "total": f + w}
-scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0) + fetch.get("k_scan_onepass", 0),
-        "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0) + write.get("k_scan_onepass", 0)}
-scan["total"] = scan["fetch"] + scan["write"]
-res["cell_scan"] = scan
-doc = {"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}
-if len(sys.argv) > 6 and sys.argv[6]:
-    doc["git_head"] = sys.argv[6]  # the build the counters were taken from (bench.py quotes it next to roofline.traffic)
-json.dump(doc, open(sys.argv[4], "w"), indent=1)
-print(json.dumps(res, indent=1)[:400])
+if __name__ == "__main__":
+    fetch, write = table(sys.argv[1]), table(sys.argv[2])
+    res = {}
+    for k, label in NAMES.items():
+        if k in fetch or k in write:
+            f, w = fetch.get(k, 0), write.get(k, 0)
+            res[label] = {"fetch": f, "write": w, "total": f + w}
+    scan = {"fetch": fetch.get("k_scan_reduce", 0) + fetch.get("k_scan_apply", 0) + fetch.get("k_scan_onepass", 0),
+            "write": write.get("k_scan_reduce", 0) + write.get("k_scan_apply", 0) + write.get("k_scan_onepass", 0)}
+    scan["total"] = scan["fetch"] + scan["write"]
+    res["cell_scan"] = scan
+    doc = {"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}
+    if len(sys.argv) > 6 and sys.argv[6]:
+        doc["git_head"] = sys.argv[6]  # the build the counters were taken from (bench.py quotes it next to roofline.traffic)
+    json.dump(doc, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(res, indent=1)[:400])

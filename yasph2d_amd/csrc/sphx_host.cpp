@@ -354,7 +354,9 @@ void HipDfsphMultiSolver::simulation_step(FluidParticleWorld& w, TimeManager& tm
             // caller appended behind them since (add_fluid_rect mid-run) is kept: the download replaces the prefix only, like the
             // single-context solver does.
             const size_t keep = w.stale_prefix;
-            if (keep > n || keep != sphx_multi_num_owned(multi_)) {
+            // (no comparison with the tiles' owned count: particles the tiles have retired — non-finite, out of every band — make it
+            // smaller than the host's stale prefix, and in rank mode it is this rank's share only; round-3 advisor finding)
+            if (keep > n) {
                 last_status = SPHX_ERR_NOT_READY;
                 last_error = "the host world was edited while it was behind the device state: call sync_world() before editing particles";
                 return;

@@ -222,6 +222,8 @@ struct Grid {
     uint32_t dir_cap = 0;
     uint2* fine = nullptr;     // cell ranges of the latest build (len() entries) + the null block (BLOCK_CELLS all-zero entries)
     uint32_t* hist = nullptr;  // all-zero between builds; receives the next build's per-cell histogram
+    uint32_t* tile_empty = nullptr;  // per scan tile: held no particle at the latest build (k_scan_onepass); tile_cap entries
+    uint32_t tile_cap = 0;
     uint32_t fine_cap = 0;     // entries allocated in fine and hist
     uint32_t bx0 = 0, by0 = 0, nbx = 0, nby = 0, nblk = 0;
     std::vector<uint8_t> cover;  // dynamic grid, host side: 0 uncovered / 1 interior / 2 fringe per block of the rectangle (static grid: 0 / 1)

@@ -297,8 +297,7 @@ __device__ __forceinline__ double block_sum_f64(double s) {
 }
 __device__ __forceinline__ uint32_t block_max_u32(uint32_t b) {
     __shared__ uint32_t wm[4];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
+    b = wave_max_u32(b);
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
     __syncthreads();
     const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
@@ -421,12 +420,18 @@ constexpr uint32_t SCAN_AGG = 1u, SCAN_PREFIX = 2u;
 __device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t flag, uint32_t value) {
     return ((unsigned long long)epoch << 32) | ((unsigned long long)flag << 30) | value;  // value < 2^30 (contexts hold < 2^28 slots)
 }
+// Round 4: a tile of the table that holds no particle costs its 16 KiB of histogram reads and nothing else.  The histogram is
+// only re-zeroed where it was not zero (per thread), and the tile's 32 KiB of cell ranges are not rewritten when the tile was
+// empty at the previous build of this grid as well (tile_empty[], kept by this kernel; set for every tile when set_directory zeroes
+// the table): whoever looks at a cell of such a tile only needs start == end, which stale-but-equal entries still say.  The dam
+// break's table is a third fringe and empty interior blocks at t = 0 and more than half once the splashes have spread it.
 __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in, uint2* __restrict__ out, uint32_t len,
                                                        unsigned long long* __restrict__ state, uint32_t epoch,
                                                        DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total, Mailbox* __restrict__ mb,
-                                                       uint32_t mb_seq) {
+                                                       uint32_t mb_seq, uint32_t* __restrict__ tile_empty) {
     const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * SCAN1_TILE;
+    const uint32_t was_empty = tile_empty[bid];
     uint32_t v[SCAN1_ITEMS];
     uint32_t s = 0;
     const uint32_t t0 = base + threadIdx.x * SCAN1_ITEMS;
@@ -440,21 +445,27 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
             v[4 * k + 1] = q.y;
             v[4 * k + 2] = q.z;
             v[4 * k + 3] = q.w;
-            p4[k] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) s += v[k];
+        if (s != 0u) {
+#pragma unroll
+            for (uint32_t k = 0; k < SCAN1_ITEMS / 4; ++k) p4[k] = make_uint4(0, 0, 0, 0);
         }
     } else {
 #pragma unroll
         for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) {
             v[k] = (t0 + k < len) ? in[t0 + k] : 0;
-            if (t0 + k < len) in[t0 + k] = 0;
+            if (t0 + k < len && v[k] != 0u) in[t0 + k] = 0;
+            s += v[k];
         }
     }
-#pragma unroll
-    for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) s += v[k];
     uint32_t total;
     uint32_t run = block_excl_scan_256(s, &total);
+    const bool skip_out = total == 0u && was_empty != 0u;  // (workgroup-uniform)
     __shared__ uint32_t excl_s;
     if (threadIdx.x == 0) {
+        tile_empty[bid] = total == 0u ? 1u : 0u;
         excl_s = 0;
         __hip_atomic_store(&state[bid], scan_word(epoch, bid == 0 ? SCAN_PREFIX : SCAN_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -477,10 +488,7 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
             const uint32_t val = (uint32_t)st & 0x3FFFFFFFu;
             const unsigned long long known = __ballot(((st >> 30) & 3u) == SCAN_PREFIX);
             const uint32_t first = known ? (uint32_t)__ffsll((long long)known) - 1u : 63u;
-            uint32_t part = lane <= first ? val : 0u;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-            excl += part;
+            excl += wave_sum_u32(lane <= first ? val : 0u);
             if (known) break;
             j -= 64;
         }
@@ -499,6 +507,8 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
         __syncthreads();
         publish_common(scal, mb, mb_seq);
     }
+    if (skip_out) return;
+    if (skip_out) return;
     if (full) {
         uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
 #pragma unroll
@@ -568,7 +578,7 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
         if (f && (__hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&scal->flags, f);
         cidx[i] = idx;
     }
-    const uint32_t prev = __shfl_up(idx, 1, 64);
+    const uint32_t prev = dpp_mov<0x138>(idx, idx);  // wave_shr:1 — the cell of the lane below (lane 0: its own; unused)
     const bool head = (lane == 0) || (idx != prev);
     const unsigned long long mask = __ballot(head);
     const uint32_t start = 63u - (uint32_t)__clzll(mask & (~0ull >> (63u - lane)));
@@ -1606,7 +1616,9 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
 #pragma unroll
     for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
-    h.lw0 = b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
+    // (a workgroup past the last particle — the grid is rounded up to a multiple of eight — stages slot 0: its clamped loads must
+    // not reach past the [N|B] arrays)
+    h.lw0 = active && b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
     return h;
 }
@@ -1828,9 +1840,7 @@ __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict
 // The same with the four per-wavefront words in memory the caller has finished with (k_nonpressure: its staging area is 20 KiB to
 // the byte — with 16 bytes of its own for this reduction a workgroup no longer fits eight times into the CU's 160 KiB).
 __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict__ scal, uint32_t vslot, uint32_t* wm) {
-    uint32_t b = __float_as_uint(vsq);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_down((int)b, d, 64));
+    const uint32_t b = wave_max_u32(__float_as_uint(vsq));
     __syncthreads();  // every wavefront has left the staging area
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
     __syncthreads();
@@ -1842,10 +1852,8 @@ __device__ __forceinline__ void block_vmax_add(float vsq, DevScalars* __restrict
 // called by a whole wavefront; every lane returns the maximum
 __device__ __forceinline__ uint32_t wave_vmax_get(const DevScalars* __restrict__ scal, uint32_t vslot) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t b = lane < STRIPES ? scal->vstripe[lane].vmax[vslot & 3u] : 0u;  // plain load, as in residual_stripe_load
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
-    return b;
+    const uint32_t b = lane < STRIPES ? scal->vstripe[lane].vmax[vslot & 3u] : 0u;  // plain load, as in residual_stripe_load
+    return wave_max_u32(b);
 }
 // The reader's workgroup 0 (its first wavefront) clears the slot that comes into use two reductions later and publishes.
 __device__ __forceinline__ void vmax_publish(DevScalars* __restrict__ scal, const VmaxArgs& va, uint32_t bits, const TimerLaw& law, unsigned long long ns,
@@ -1900,11 +1908,9 @@ __device__ __forceinline__ void residual_stripe_load(const DevScalars* __restric
     lo = lane < STRIPES ? scal->stripe[lane].res_lo : 0ull;
 }
 __device__ __forceinline__ void residual_wave_reduce(unsigned long long& hi, unsigned long long& lo) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        hi += __shfl_xor(hi, d, 64);
-        lo += __shfl_xor(lo, d, 64);
-    }
+    // (cumulative sums of 32 stripes; they stay far below 2^58 for any run length that matters: every term is < 2^32 resp. < 2^22)
+    hi = wave_sum_u63(hi);
+    lo = wave_sum_u63(lo);
 }
 // cumulative sums now and after the previous iteration -> the residual sum of this iteration as the f64 the host works with
 __device__ __forceinline__ double residual_sum_f64(unsigned long long hi, unsigned long long lo, unsigned long long hi0, unsigned long long lo0) {
@@ -2168,9 +2174,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         const NbStaged<PredRec> st = nb_stage_load(h, load_pred);
         __shared__ float dt_s;
         if (pa.va.enabled && threadIdx.x < 64) {
-            uint32_t b = vb;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+            const uint32_t b = wave_max_u32(vb);
             const unsigned long long ns = timer_law_step_ns(pa.law, sqrtf(__uint_as_float(b)));
             const float d = duration_as_secs_f32(ns);
             if (threadIdx.x == 0) dt_s = d;

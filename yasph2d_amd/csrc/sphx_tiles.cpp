@@ -146,6 +146,8 @@ struct Comm {
     virtual int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) = 0;
     virtual int allreduce(const double* in, int n, int op, double* out) = 0;  // op 0 sum, 1 max; same bits on every rank
     virtual void abort() {}  // this tile has failed: the tiles waiting for it in an all-reduce are released (they fail too)
+    // the run is poisoned (a queued receive may never complete): tear the transport down WITHOUT waiting for what is enqueued on it
+    virtual void abandon() {}
     virtual const char* name() const = 0;
 };
 
@@ -180,6 +182,8 @@ struct RcclComm : Comm {
     int (*p_get_uid)(Uid*) = nullptr;
     int (*p_init)(void**, int, Uid, int) = nullptr;
     int (*p_destroy)(void*) = nullptr;
+    int (*p_abort)(void*) = nullptr;
+    bool abandoned = false;
     int (*p_send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*p_recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*p_gstart)() = nullptr;
@@ -221,6 +225,7 @@ struct RcclComm : Comm {
             p_get_uid = (int (*)(Uid*))dlsym(lib, "ncclGetUniqueId");
             p_init = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
             p_destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+            p_abort = (int (*)(void*))dlsym(lib, "ncclCommAbort");
             p_send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclSend");
             p_recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclRecv");
             p_gstart = (int (*)())dlsym(lib, "ncclGroupStart");
@@ -273,8 +278,15 @@ struct RcclComm : Comm {
         return SPHX_OK;
     }
     void abort() override { sphx_shm_abort(shm); }
+    // ncclCommDestroy waits for the operations enqueued on the communicator — for the very receive a poisoned run will never see
+    // completed (round-3 advisor finding).  ncclCommAbort does not wait; without it the communicator is leaked rather than joined.
+    void abandon() override { abandoned = true; }
     ~RcclComm() override {
-        if (comm && p_destroy) p_destroy(comm);
+        if (comm && abandoned) {
+            if (p_abort) p_abort(comm);
+        } else if (comm && p_destroy) {
+            p_destroy(comm);
+        }
         if (shm) sphx_shm_close(shm);
     }
     int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
@@ -452,8 +464,10 @@ struct TileDriver {
 
     ~TileDriver() {
         if (ctx && poisoned && comm && comm->world > 1 && std::string(comm->name()).find("in-process") == std::string::npos) {
-            // one process per tile and the run has failed: a queued receive may never complete — do not wait for the stream, the
-            // process is about to report the error and exit
+            // one process per tile and the run has failed: a queued receive may never complete — do not wait for the stream (the
+            // context, its stream and the exchange buffers are deliberately left to process exit) and do not let the communicator
+            // wait for it either; the process is about to report the error and exit
+            comm->abandon();
             ctx = nullptr;
             return;
         }
