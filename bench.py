@@ -566,13 +566,6 @@ def main():
         it = iteration_stats(stats)
         kbar = float(np.mean([s["neighbor_entries"] for s in stats])) / n
         rbar = float(np.mean([s.get("remote_entries", 0) for s in stats])) / n
-        if roof and roof["kernel"].startswith("neighbor_build+density_alpha+"):
-            # continuity with the round-2 figures: that round priced the fused build at 36 + L (resp. 40 + L) bytes per particle with 16-bit
-            # list entries and a 32-bit count word, L = 2 k + 4 r; this round's lists and arrays are smaller, and so is `achieved`
-            l2 = 2.0 * kbar + 4.0 * rbar + 4.0 / 256
-            b2 = ((36.0 if roof["kernel"].endswith("density_change") else 40.0) + l2) * n
-            roof["round2_byte_definition"] = {"algorithmic_bytes_per_launch": b2, "achieved": b2 / (roof["avg_launch_ms"] * 1e-3) / 1e9,
-                                              "frac": b2 / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         res = dict(scale=scale, n=n, n_boundary=len(boundary), elapsed=elapsed, steps=steps, warmup=warmup, skip_steps=skip_steps, it=it, kbar=kbar, rbar=rbar,
                    roof=roof, value=n * steps / elapsed, ms_per_step=elapsed / steps * 1e3, model=step_model(kbar, rbar, it, n, steps, elapsed, True))
         if solver is not None and hasattr(solver, "close"):

@@ -1489,22 +1489,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             // * entries past the staged rows go to global memory in a (rarely entered) block after the append.
             const uint32_t eb = (e[t] << 3) + nw0b;  // (one shift-add each)
             uint32_t ab = (s[t] << 3) + nw0b;
-            while (ab != eb) {
+            // One trip over W candidates (W = 4: two ds_read2_b64; W = 2: one).  The first trip of a cell is four wide; what is left
+            // of a cell with five or six particles — the wavefront makes that trip when ANY of its lanes has such a cell, i.e. always
+            // once the fluid is compressed (3.7 particles per cell after the impact, 1.9 trips per cell and wavefront with four-wide
+            // trips only) — goes in two-wide trips at 24 instead of 42 vector instructions.
+            auto trip = [&](auto width) {
+                constexpr uint32_t W = decltype(width)::value;
                 const uint32_t rem = eb - ab;  // bytes of candidates left in this cell (>= 8)
                 const char* const base = (const char*)win + min(ab, wlen_b);  // below or beyond the window: the pad slots
-                const f32x4 p01 = *(lds_cf4a8*)base, p23 = *(lds_cf4a8*)(base + 16);
-                float2 pj[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
+                float2 pj[W];
+                {
+                    const f32x4 p01 = *(lds_cf4a8*)base;
+                    pj[0] = make_float2(p01.x, p01.y);
+                    pj[1] = make_float2(p01.z, p01.w);
+                    if (W == 4) {
+                        const f32x4 p23 = *(lds_cf4a8*)(base + 16);
+                        pj[W - 2] = make_float2(p23.x, p23.y);
+                        pj[W - 1] = make_float2(p23.z, p23.w);
+                    }
+                }
                 if (ab >= far_lim) {
-                    // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL four from
-                    // global memory (one address, four loads with immediate offsets; what the window holds is the same data, and the
+                    // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL of them from
+                    // global memory (one address, loads with immediate offsets; what the window holds is the same data, and the
                     // slots past the run's end are never accepted — posA is allocated four slots longer than the particle arrays)
                     const float2* const gp = (const float2*)((const char*)posA + (w0b + ab));
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) pj[u] = gp[u];
+                    for (uint32_t u = 0; u < W; ++u) pj[u] = gp[u];
                 }
-                bool acc[4];
+                bool acc[W];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
+                for (uint32_t u = 0; u < W; ++u) {
                     // both components in one packed instruction each (v_pk_add_f32 / v_pk_mul_f32: plain IEEE operations, no fusion)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
@@ -1514,26 +1528,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 }
                 // every candidate is WRITTEN to the row the running address points at; a rejected one is overwritten by the next accepted
                 // one (the address has not moved), an accepted one is safe (the address moves past it).  The dump row absorbs the rest.
-                uint32_t a[5];
+                uint32_t a[W + 1];
                 a[0] = ta;
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) a[u + 1] = a[u] + (acc[u] ? ROW_B : 0u);
+                for (uint32_t u = 0; u < W; ++u) a[u + 1] = a[u] + (acc[u] ? ROW_B : 0u);
                 if (!__any(ta > t_fast)) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) lds_store_u32(a[u], ab + 8u * u);
+                    for (uint32_t u = 0; u < W; ++u) lds_store_u32(a[u], ab + 8u * u);
                 } else {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) lds_store_u32(min(a[u], t_dump), ab + 8u * u);
-                    if (a[4] > t_dump) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
+                    for (uint32_t u = 0; u < W; ++u) lds_store_u32(min(a[u], t_dump), ab + 8u * u);
+                    if (a[W] > t_dump) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
 #pragma unroll
-                        for (uint32_t u = 0; u < 4; ++u) {
+                        for (uint32_t u = 0; u < W; ++u) {
                             const uint32_t row = (a[u] - t_base) / ROW_B;
                             if (acc[u] && row >= STAGE_ROWS && row < MAX_NEIGHBORS) list[ell_index(i, row)] = entry_slot(ab + 8u * u, w0);
                         }
                     }
                 }
-                ta = a[4];
-                ab = (uint32_t)min((int32_t)(ab + 32u), (int32_t)eb);
+                ta = a[W];
+                ab = (uint32_t)min((int32_t)(ab + 8u * W), (int32_t)eb);
+            };
+            if (ab != eb) {
+                trip(std::integral_constant<uint32_t, 4>{});
+                while (ab != eb) trip(std::integral_constant<uint32_t, 2>{});
             }
         }
         ct = (ta - t_base) / ROW_B;
