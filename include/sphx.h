@@ -372,6 +372,16 @@ int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out
 void sphx_shm_abort(sphx_shm* h); /* this rank has failed: release the ranks that wait for it */
 void sphx_shm_close(sphx_shm* h);
 
+/* NOT the reference's behaviour — a comparison mode for multi-GPU runs.  Two things in a DFSPH run depend on how the domain is cut into
+ * tiles: the order of the particles inside a cell (the reference's par_sort_unstable_by_key leaves it open, neighborhood_search.rs:118;
+ * this build keeps them in the order of their previous index, which a tile that appends what it receives cannot reproduce) and the
+ * warm-start values, which the reference leaves bound to their slot when the particles are re-sorted (dfsph.rs:512) — a slot means
+ * nothing across tiles, so tiles let them travel with the particle.  With this switch a context orders the particles of a cell by their
+ * persistent id (sphx_download's particle_id) and moves the warm-start values with them: a single context, any sphx_multi tiling and
+ * the oracle in the same mode then compute the same run (tests/test_gpu_tiles_full.py).  Off by default; tile contexts take the switch
+ * for the cell order (their warm-start values always travel). */
+int sphx_set_tiling_invariant(sphx_ctx* ctx, int on);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 int sphx_synchronize(sphx_ctx* ctx);
 /* the latest neighbour build of this context: particles it ran over, list entries in total, entries outside the workgroup windows */

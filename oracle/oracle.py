@@ -100,6 +100,8 @@ def lib(omp=False):
         "orc_update_densities": (None, [vp, i32]),
         "orc_compute_alpha": (None, [vp]),
         "orc_dfsph_set_fixed_iterations": (None, [vp, u32, u32]),
+        "orc_dfsph_set_warmstart_travel": (None, [vp, i32]),
+        "orc_set_tiling_invariant": (None, [vp, i32]),
         "orc_dfsph_set_tolerances": (None, [vp, f32, u32, f32, u32]),
         "orc_dfsph_clear_cached": (None, [vp]),
         "orc_dfsph_step": (None, [vp, C.POINTER(StepStats)]),
@@ -191,6 +193,16 @@ class Oracle:
 
     def set_fixed_iterations(self, nd, nv):
         self.L.orc_dfsph_set_fixed_iterations(self.h, nd, nv)
+
+    def set_tiling_invariant(self, on=True):
+        """NOT the reference's behaviour (sphx_set_tiling_invariant's twin): the particles of a cell are ordered by persistent id and the
+        warm-start values travel with their particle — the two places where a run depends on how the domain is cut into tiles."""
+        self.L.orc_set_tiling_invariant(self.h, int(bool(on)))
+
+    def set_warmstart_travel(self, on=True):
+        """NOT the reference's behaviour: warmstart_kappa / warmstart_stiffness are permuted with their particle on every re-sort
+        (the reference leaves them slot-bound, dfsph.rs:512).  The mode multi-GPU tilings are compared with a single domain in."""
+        self.L.orc_dfsph_set_warmstart_travel(self.h, int(bool(on)))
 
     # --- path pieces
     def update_neighborhood(self):

@@ -364,6 +364,7 @@ struct GridProperties {  // :45-64
 struct CompactMortonCellGrid {  // :66-260
     std::vector<MortonCell> cells;
     std::vector<uint32_t> last_sorting;  // kept so callers can permute their own attributes (ids)
+    const std::vector<uint32_t>* tie_ids = nullptr;  // tiling-invariant mode: order cell mates by these (see update)
     CompactMortonCellGrid() { cells.push_back(MortonCell{0, 0xFFFFFFFFu}); }  // :80-87
 
     // pooled scratch (scratch_buffer.rs:64-90): one buffer per element size, swapped with the sorted array
@@ -397,11 +398,20 @@ struct CompactMortonCellGrid {  // :66-260
             cell_indices[i] = grid.position_to_cidx(positions[i]);
         }
         auto by_cell = [&](uint32_t a, uint32_t b) { return cell_indices[a] < cell_indices[b]; };
+        // oracle extra (tiling-invariant mode, NOT the reference): ties inside a cell by persistent id (owner bit of the tile path masked)
+        const std::vector<uint32_t>* tid = tie_ids;
+        auto by_cell_id = [&](uint32_t a, uint32_t b) {
+            return cell_indices[a] != cell_indices[b] ? cell_indices[a] < cell_indices[b] : ((*tid)[a] & 0x7FFFFFFFu) < ((*tid)[b] & 0x7FFFFFFFu);
+        };
+        if (tid && tid->size() == n) {
+            std::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell_id);
+        } else {
 #ifdef ORC_OMP
-        __gnu_parallel::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell);  // :116-118 (parallel)
+            __gnu_parallel::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell);  // :116-118 (parallel)
 #else
-        std::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell);
+            std::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell);
 #endif
+        }
         apply_sorting(particle_indices, positions);  // :121-140
         for (auto* a : attrs_vec) apply_sorting(particle_indices, *a);
         for (auto* a : attrs_real) apply_sorting(particle_indices, *a);
@@ -627,6 +637,7 @@ struct World {
     NeighborhoodSearch neighborhood;
     V2 gravity;
     bool boundary_changed;
+    bool tie_by_id = false;  // oracle extra (orc_set_tiling_invariant): cell mates ordered by persistent id instead of by previous index
 
     void init(const OrcParams& p) {  // :104-127, :53-64
         particle_density = p.particle_density;
@@ -650,6 +661,7 @@ struct World {
         }
         std::vector<std::vector<uint32_t>*> au;
         au.push_back(&ids);
+        neighborhood.cellgrid_dynamic.tie_ids = tie_by_id ? &ids : nullptr;
         neighborhood.update_dynamic(positions, av, ar, au, boundary_particles);  // :254-260
     }
 
@@ -735,6 +747,10 @@ struct DFSPHSolver {  // dfsph.rs:16-41
     std::vector<V2> pool_predicted, pool_accel;
     std::vector<Real> pool_error;
     uint32_t fixed_density_iterations = 0, fixed_divergence_iterations = 0;  // oracle extra: parity mode
+    // oracle extra, NOT the reference's behaviour (dfsph.rs:512 permutes the predicted velocities only: warmstart_kappa / _stiffness stay
+    // slot-bound): the warm-start values are permuted with their particle.  A multi-GPU tiling cannot keep values slot-bound across tiles,
+    // so its runs are compared with a single domain in THIS mode (orc_dfsph_set_warmstart_travel).
+    bool warmstart_travels = false;
 
     void init(Real h) {  // :43-61
         viscosity_model.init(h);
@@ -1046,7 +1062,10 @@ struct DFSPHSolver {  // dfsph.rs:16-41
 #endif
             for (long i = 0; i < (long)n; ++i) w.positions[i] = w.positions[i] + predicted_velocities[i] * dt;
         }
-        w.update_neighborhood_datastructure({&predicted_velocities}, {});  // :512
+        if (warmstart_travels)
+            w.update_neighborhood_datastructure({&predicted_velocities}, {&warmstart_kappa, &warmstart_stiffness});
+        else
+            w.update_neighborhood_datastructure({&predicted_velocities}, {});  // :512
         w.update_densities(kernel);                                        // :516
         compute_alpha_factors(w);                                          // :518
         correct_divergence_error(dt, w, predicted_velocities, st);         // :521
@@ -1323,6 +1342,12 @@ void orc_compute_alpha(OrcSim* s) {
 void orc_dfsph_set_fixed_iterations(OrcSim* s, uint32_t nd, uint32_t nv) {
     s->dfsph.fixed_density_iterations = nd;
     s->dfsph.fixed_divergence_iterations = nv;
+}
+void orc_dfsph_set_warmstart_travel(OrcSim* s, int on) { s->dfsph.warmstart_travels = on != 0; }
+// tiling-invariant mode = cell mates ordered by persistent id + travelling warm-start values (sphx_set_tiling_invariant's twin)
+void orc_set_tiling_invariant(OrcSim* s, int on) {
+    s->world.tie_by_id = on != 0;
+    s->dfsph.warmstart_travels = on != 0;
 }
 void orc_dfsph_set_tolerances(OrcSim* s, float max_avg_density_error, uint32_t max_density_iters, float max_divergence_error,
                               uint32_t max_divergence_iters) {

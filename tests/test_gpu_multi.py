@@ -333,6 +333,51 @@ def test_sphx_multi_four_tiles_at_4M_against_the_single_context():
     m.close()
 
 
+def test_sphx_multi_equals_the_single_context_bit_for_bit_in_tiling_invariant_mode():
+    """The C++ tile loop (sphx_multi) on 2 x 2 tiles of ONE device against the single context, both in tiling-invariant mode
+    (sphx_set_tiling_invariant: cell mates ordered by persistent id, warm-start values travel).  4 M particles from a skewed cut so that
+    particles migrate and the cuts move; fixed 2 + 2 iterations per step so that BOTH warm starts fire on every step from the second on
+    (the adaptive run of this scene needs none in its first steps).  Bit-equal positions and velocities after 12 steps, every particle
+    owned exactly once."""
+    pos, boundary = dam_break(float(np.sqrt(4.0e6 / 4050.0)))
+    n, steps = len(pos), 12
+    params = y.default_params(fixed_iterations=(2, 2))
+    ctx = y.SphxContext(params)
+    ctx.set_tiling_invariant(True)
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    warm = 0
+    for _ in range(steps):
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
+        st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(np.float32(0.01), vmax)))
+        warm += st["warmstart_divergence"] + st["warmstart_density"]
+    assert warm >= 2 * (steps - 1)
+    ref = by_id({kk: vv for kk, vv in ctx.download(density=False).items() if kk in ("ids", "pos", "vel")})
+    ctx.close()
+    cx, cy = cell_coord(pos, 0), cell_coord(pos, 1)
+    xs = np.sort(cx)
+    xcuts = [0, int(xs[int(0.3 * n)]), 65536]
+    ycuts = []
+    for ix in range(2):
+        col = cy[(cx >= xcuts[ix]) & (cx < xcuts[ix + 1])]
+        ycuts.append([0, int(np.sort(col)[len(col) // 2]), 65536])
+    m = MultiSolver(y.default_params(fixed_iterations=(2, 2)), devices=[0, 0, 0, 0], rebalance_every=4)
+    m.set_tiling_invariant(True)
+    m.set_grid(xcuts, np.array(ycuts, np.uint32))
+    m.set_boundary(boundary)
+    m.upload(pos)
+    t2 = y.TimeManager()
+    m.steps(t2, steps)
+    a = by_id({k: v for k, v in m.download().items() if k in ("ids", "pos", "vel")})
+    np.testing.assert_array_equal(a["ids"], np.arange(n, dtype=np.uint32))
+    assert_bits_equal(a["pos"], ref["pos"], "positions, tiling-invariant mode")
+    assert_bits_equal(a["vel"], ref["vel"], "velocities, tiling-invariant mode")
+    assert t2.simulation_step_ns() == timer.simulation_step_ns()
+    assert m.info()["rebalances"] >= 2
+    m.close()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_tile_classification_by_the_last_density_correction_changes_nothing(monkeypatch, overlap):
     """The density loop's last correction holds the advected positions: in a tile it counts the cells of the particles the tile keeps

@@ -15,8 +15,9 @@ neighborhood_search.rs:348-393), by persistent particle id:
                    index) behind its cell mates, whereas the single context keeps it where its previous sorted index puts it —
                    the neighbour SETS stay equal, the order of the per-particle sums and thus the last bits do not.
 
-The tile-vs-single run through warm starts (where tile mode deliberately lets kappa / stiffness travel with the particle,
-DESIGN.md §7) states its tolerance in test_tiles_vs_single_through_warm_starts.
+Both dependencies on the tiling — that order, and the warm-start values, which tile mode lets travel with the particle —
+go away in tiling-invariant mode (sphx_set_tiling_invariant): test_tiles_equal_the_single_context_through_warm_starts_in_tiling_invariant_mode
+compares tiles and single context bit for bit through the impact.
 """
 import threading
 
@@ -90,7 +91,7 @@ def run_single(pos, boundary, steps_list, sample_ids):
     return out
 
 
-def run_tiles(pos, boundary, world, layout_factory, steps_list, sample_ids, halo=16, cap=None):
+def run_tiles(pos, boundary, world, layout_factory, steps_list, sample_ids, halo=16, cap=None, invariant=False, keep_stats=False):
     shared = ThreadComm.Shared(world)
     res, errs = [None] * world, []
     n = len(pos)
@@ -98,13 +99,18 @@ def run_tiles(pos, boundary, world, layout_factory, steps_list, sample_ids, halo
     def work(r):
         try:
             ctx = y.SphxContext()
+            if invariant:
+                ctx.set_tiling_invariant(True)
             t = TiledDFSPH(GpuTileBackend(ctx), ThreadComm(shared, r), layout_factory(), halo=halo, adaptive_halo=True, cap_records=cap)
             t.setup(pos, None, None, boundary)
             timer = y.TimeManager()
             out, done = {}, 0
+            all_stats = []
             for k in steps_list:
                 for _ in range(k - done):
                     st = t.step(timer)
+                    if keep_stats:
+                        all_stats.append(dict(st, dt_ns=timer.simulation_step_ns()))
                 done = k
                 d = t.b.download()
                 own = d["owned"]
@@ -117,6 +123,8 @@ def run_tiles(pos, boundary, world, layout_factory, steps_list, sample_ids, halo
                     rec["nb_sample"] = np.nonzero(mine)[0]
                     rec["nb"] = neighbour_hashes(ctx, d["ids"], loc[sample_ids[mine]])
                 out[k] = rec
+            if keep_stats:
+                out["all_stats"] = all_stats
             res[r] = out
             ctx.close()
         except BaseException as e:  # noqa: BLE001
@@ -242,33 +250,53 @@ def test_config4_128M_particles_8_strips():
     assert max(own) < 1.1 * (len(pos) / 8), f"quantile cuts must balance the strips: {own}"
 
 
-def test_tiles_vs_single_through_warm_starts():
-    """Tile mode lets warmstart_kappa / warmstart_stiffness travel with their particle; the single context (like the reference,
-    dfsph.rs:512) leaves them slot-bound.  Once a warm start has fired the two runs are different — equally valid — discretisations.
-    Bound what that costs: through the impact of the reference scene (260 steps, warm starts on most of the later ones — the
-    splash amplifies any difference chaotically) total mechanical energy agrees to 0.5 % and the centre of mass of the fluid to one
-    particle spacing (measured: half a spacing)."""
+def test_tiles_equal_the_single_context_through_warm_starts_in_tiling_invariant_mode():
+    """Multi-GPU parity through warm starts (replaces a 0.5 % energy bound).  Tile mode lets warmstart_kappa /
+    warmstart_stiffness travel with their particle (the reference leaves them slot-bound, dfsph.rs:512 — a slot means nothing across
+    tiles), and a tile sorts what it receives behind what it holds, so the order inside a cell differs from the single context's.
+    sphx_set_tiling_invariant removes both dependencies (cell mates ordered by persistent id, warm-start values travel).  In that
+    mode, through the impact of the reference scene (260 steps, warm starts on most of the later ones):
+      * the single context equals the oracle in the same mode bit for bit (the switch itself is parity-checked),
+      * x-strips (the cut the collapsing column flows across) and 2 x 2 tiles equal the single context BIT FOR BIT: positions, velocities,
+        iteration counts, time steps."""
+    from oracle.oracle import Oracle
+
     pos, boundary = dam_break(1.0)
-    steps = 260
+    n, steps = len(pos), 260
+    o = Oracle()
+    o.set_tiling_invariant(True)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
     ctx = y.SphxContext()
+    ctx.set_tiling_invariant(True)
     ctx.set_boundary(boundary)
     ctx.upload(pos)
     timer = y.TimeManager()
     it_single, warm = [], 0
     for _ in range(steps):
         vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
-        st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(np.float32(0.01), vmax)))
-        it_single.append(st["divergence_iterations"])
+        dt_ns = timer.update_simulation_step(np.float32(0.01), vmax)
+        st = ctx.step_finish(y.duration_as_secs_f32(dt_ns))
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns()
+        assert (st["density_iterations"], st["divergence_iterations"]) == (so["density_iterations"], so["divergence_iterations"])
+        it_single.append((st["density_iterations"], st["divergence_iterations"], dt_ns))
         warm += st["warmstart_divergence"] + st["warmstart_density"]
-    assert warm > 30
+    assert warm > 100
     d = ctx.download()
-    axis, cuts = 1, quantile_cuts(cell_coord(pos, 1), 2)
-    tiles = run_tiles(pos, boundary, 2, lambda: StripLayout(axis, cuts), [steps], np.zeros(0, np.int64), halo=16)
-    p, v = merge(tiles, steps, len(pos))
-
-    def energy(pp, vv):
-        return float((0.5 * (vv.astype(np.float64) ** 2).sum(1) + 9.81 * pp[:, 1].astype(np.float64)).sum())
-
-    e_single, e_tiles = energy(d["pos"], d["vel"]), energy(p, v)
-    assert abs(e_tiles - e_single) < 5e-3 * abs(e_single)
-    assert np.abs(p.astype(np.float64).mean(0) - d["pos"].astype(np.float64).mean(0)).max() < 0.0111
+    inv, oinv = np.argsort(d["ids"]), np.argsort(o.ids())
+    sp, sv = d["pos"][inv], d["vel"][inv]
+    assert np.array_equal(sp.view(np.uint32), o.positions()[oinv].view(np.uint32)), "single context vs oracle, tiling-invariant mode: positions"
+    assert np.array_equal(sv.view(np.uint32), o.velocities()[oinv].view(np.uint32)), "single context vs oracle, tiling-invariant mode: velocities"
+    ss = ctx.download_solver_state()  # (the warm-start values have travelled with their particles on both sides)
+    assert np.array_equal(ss["kappa"][inv].view(np.uint32), o.kappa()[oinv].view(np.uint32))
+    assert np.array_equal(ss["stiffness"][inv].view(np.uint32), o.stiffness()[oinv].view(np.uint32))
+    ctx.close()
+    cuts = quantile_cuts(cell_coord(pos, 0), 2)
+    for world, factory in ((2, lambda: StripLayout(0, cuts)), (4, lambda: GridLayout.quantile(pos, 2, 2))):
+        tiles = run_tiles(pos, boundary, world, factory, [steps], np.zeros(0, np.int64), halo=16, invariant=True, keep_stats=True)
+        p, v = merge(tiles, steps, n)
+        for out in tiles:
+            assert [(s["density_iterations"], s["divergence_iterations"], s["dt_ns"]) for s in out["all_stats"]] == it_single
+        assert np.array_equal(p.view(np.uint32), sp.view(np.uint32)), f"{world} tiles vs single context: positions differ, max {np.abs(p - sp).max()}"
+        assert np.array_equal(v.view(np.uint32), sv.view(np.uint32)), f"{world} tiles vs single context: velocities differ, max {np.abs(v - sv).max()}"

@@ -143,6 +143,11 @@ class SphxContext:
     def synchronize(self):
         self._chk(self.L.sphx_synchronize(self.h))
 
+    def set_tiling_invariant(self, on=True):
+        """sphx_set_tiling_invariant: cell mates ordered by persistent id, warm-start values travel with their particle (a comparison
+        mode for multi-GPU runs; not the reference's behaviour)."""
+        self._chk(self.L.sphx_set_tiling_invariant(self.h, int(bool(on))))
+
     def download(self, pos=True, vel=True, density=True, ids=True):
         n = self.n
         out = {}

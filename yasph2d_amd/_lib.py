@@ -155,6 +155,7 @@ SIGNATURES = {
     "sphx_shm_abort": (None, [_vp]),
     "sphx_sub_run_ahead": (_i, [_vp, C.c_float]),
     "sphx_tile_carry_warmstart": (_i, [_vp, _i, _i]),
+    "sphx_set_tiling_invariant": (_i, [_vp, _i]),
     "sphx_tile_defer_advect": (_i, [_vp, _i]),
     "sphx_build_stats": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_shm_close": (None, [_vp]),

@@ -320,6 +320,9 @@ struct sphx_ctx {
     bool tile_defer_advect = false;  // sphx_tile_defer_advect
     float sub_ahead_dt = 0.0f;  // sphx_sub_run_ahead: the next sphx_sub_iteration queues the next step's non-pressure pass behind its kernels
     bool tile_carry_kappa = true, tile_carry_stiff = true;  // sphx_tile_carry_warmstart: which warm-start arrays the re-grid's gather moves
+    // sphx_set_tiling_invariant (NOT the reference's behaviour): the particles of a cell are ordered by persistent id and the warm-start
+    // values travel with their particle — the two places where a run depends on how the domain is cut into tiles
+    bool tiling_invariant = false;
     int run_ahead = 1;
 #ifndef SPHX_DEFAULT_FUSE_PREDICT
 #define SPHX_DEFAULT_FUSE_PREDICT 1

@@ -645,6 +645,10 @@ struct GatherArgs {
     uint32_t fix_owner;
     float cell_inv, gmin_x, gmin_y;  // Consts of cell_of()
     TileRect own;
+    // sphx_set_tiling_invariant: the particles of a cell are ordered by their persistent id (u_in, owner bit masked) instead of by
+    // their previous index — an order every tiling of the domain arrives at (a tile appends what it receives behind what it holds,
+    // so "previous index" means something else on every tile)
+    uint32_t rank_by_id;
 };
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
@@ -679,7 +683,16 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     uint32_t e = se.y;
     if (e > n) e = n;
     uint32_t dst;
-    if (e - s <= RANK_LOOP_MAX) {
+    if (e - s <= RANK_LOOP_MAX && a.rank_by_id && a.u_in) {
+        // (the tiling-invariant order: by persistent id; not the hot path — a test and comparison mode)
+        const uint32_t me = id & 0x7FFFFFFFu;
+        uint32_t rank = 0;
+        for (uint32_t k = s; k < e; ++k) {
+            const uint32_t j = order[k];
+            rank += (j != i && j < n_in && (a.u_in[j] & 0x7FFFFFFFu) < me) ? 1u : 0u;
+        }
+        dst = s + rank;
+    } else if (e - s <= RANK_LOOP_MAX) {
         uint32_t rank = 0;
 #pragma unroll
         for (int d = -RANK_WIN; d <= RANK_WIN; ++d) {

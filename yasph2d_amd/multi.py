@@ -207,6 +207,12 @@ class MultiSolver:
         d["transport"] = i.transport.decode()
         return d
 
+    def set_tiling_invariant(self, on=True):
+        """sphx_set_tiling_invariant on every local tile: cell mates ordered by persistent id (the tiles' warm-start values always travel).
+        A single context and the oracle in the same mode then compute the same run, bit for bit (a comparison mode)."""
+        for k in range(self.info()["local_tiles"]):
+            self.tile_context(k).set_tiling_invariant(on)
+
     def tile_context(self, k=0):
         """Borrowed SphxContext view of a local tile (inspection, profiling)."""
         from . import SphxContext
