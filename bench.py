@@ -84,7 +84,7 @@ import json, os, sys, time
 sys.path.insert(0, sys.argv[1])
 import numpy as np
 import yasph2d_amd as y            # host-side scene generator only (no GPU call)
-from oracle.oracle import Oracle, lib
+from oracle.oracle import Oracle, lib, phase_seconds
 scale, budget_s, max_steps = float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
 w = y.FluidParticleWorld()
 w.reset_fluid(scale)
@@ -97,6 +97,7 @@ for name, allpar in (("port", 0), ("all_parallel", 1)):
     o.set_boundary(boundary)
     o.set_particles(pos)
     o.dfsph_step()                 # includes the warm-up block, like the GPU warm-up steps; first touch of the pooled vectors
+    L.orc_phase_reset()
     t0 = time.perf_counter()
     steps = 0
     while steps < max_steps:
@@ -105,7 +106,7 @@ for name, allpar in (("port", 0), ("all_parallel", 1)):
         if time.perf_counter() - t0 > budget_s:
             break
     el = time.perf_counter() - t0
-    out[name] = {"value": len(pos) * steps / el, "steps": steps, "seconds": el}
+    out[name] = {"value": len(pos) * steps / el, "steps": steps, "seconds": el, "phase_seconds_per_step": {k: v / steps for k, v in phase_seconds(L).items()}}
     del o
 print("CPUBASE " + json.dumps(out))
 """
@@ -134,7 +135,11 @@ def cpu_baseline(scale, budget_s=8.0, max_steps=20):
         "cores": r["threads"],
         "kind": "port",
         "cpu": cpu_model(),
+        "phase_seconds_per_step": r["port"]["phase_seconds_per_step"],
+        "phase_note": "wall-clock seconds per step of the restatement's phases; '(serial)' = a loop the reference leaves serial (SURVEY.md 3.1), "
+                      "run on one thread in `value` and in parallel in all_parallel",
         "all_parallel": {"value": r["all_parallel"]["value"], "unit": "particle-steps/s", "cores": r["threads"],
+                         "phase_seconds_per_step": r["all_parallel"]["phase_seconds_per_step"],
                          "what": "the same restatement with the loops the reference leaves serial (cell indices, apply_sorting, max-velocity scan, "
                                  "velocity prediction, warm-start clamps) also in parallel — SURVEY 8(d)'s optional variant",
                          "sample": f"{r['all_parallel']['steps']} steps, {r['all_parallel']['seconds']:.1f} s"},

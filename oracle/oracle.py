@@ -56,6 +56,17 @@ class StepStats(C.Structure):
 
 
 _libs = {}
+# OrcPhase order of orc_phase_seconds (sph_oracle.cpp); "serial" = a loop the reference leaves serial
+PHASES = ["cell_indices (serial)", "sort", "apply_sorting (serial)", "cell_array (serial)", "neighbor_lists", "update_densities", "compute_alpha_factors",
+          "nonpressure_forces", "max_velocity+predict (serial)", "density_loop", "advect", "divergence_loop"]
+
+
+def phase_seconds(L):
+    """{phase: seconds} accumulated by this library instance since orc_phase_reset."""
+    buf = (C.c_double * len(PHASES))()
+    L.orc_phase_seconds(buf, len(PHASES))
+    return {PHASES[k]: float(buf[k]) for k in range(len(PHASES))}
+
 
 
 def lib(omp=False):
@@ -102,6 +113,8 @@ def lib(omp=False):
         "orc_dfsph_set_fixed_iterations": (None, [vp, u32, u32]),
         "orc_dfsph_set_warmstart_travel": (None, [vp, i32]),
         "orc_set_tiling_invariant": (None, [vp, i32]),
+        "orc_phase_seconds": (i32, [C.POINTER(C.c_double), i32]),
+        "orc_phase_reset": (None, []),
         "orc_dfsph_set_tolerances": (None, [vp, f32, u32, f32, u32]),
         "orc_dfsph_clear_cached": (None, [vp]),
         "orc_dfsph_step": (None, [vp, C.POINTER(StepStats)]),

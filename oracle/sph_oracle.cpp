@@ -45,6 +45,7 @@
 // =====================================================================================
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -56,6 +57,17 @@
 #endif
 
 static int g_all_parallel = 0;  // orc_set_all_parallel
+// Per-phase wall-clock seconds of the DFSPH step (bench.py's cpu_baseline reports them: which phases of the restatement scale with
+// the host's cores and which — the loops the reference leaves serial — do not).  Accumulated by the calling thread only.
+enum OrcPhase { PH_CELL_INDICES, PH_SORT, PH_APPLY_SORTING, PH_CELL_ARRAY, PH_NEIGHBOR_LISTS, PH_DENSITIES, PH_ALPHA, PH_NONPRESSURE, PH_VMAX_PREDICT,
+                PH_DENSITY_LOOP, PH_ADVECT, PH_DIVERGENCE_LOOP, PH_COUNT };
+static double g_phase_seconds[PH_COUNT];
+struct PhaseTimer {
+    int ph;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(int p) : ph(p), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { g_phase_seconds[ph] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 #ifdef ORC_OMP
 #define ORC_PRAGMA(x) _Pragma(#x)
 #define ORC_PAR_IF_ALL ORC_PRAGMA(omp parallel for schedule(static) if (g_all_parallel))
@@ -392,10 +404,13 @@ struct CompactMortonCellGrid {  // :66-260
         particle_indices.resize(n);
         std::vector<uint32_t>& cell_indices = cell_indices_pool;
         cell_indices.resize(n);
-        ORC_PAR_IF_ALL
-        for (long i = 0; i < (long)n; ++i) {  // :111-114 (serial)
-            particle_indices[i] = (uint32_t)i;
-            cell_indices[i] = grid.position_to_cidx(positions[i]);
+        {
+            PhaseTimer pt(PH_CELL_INDICES);
+            ORC_PAR_IF_ALL
+            for (long i = 0; i < (long)n; ++i) {  // :111-114 (serial)
+                particle_indices[i] = (uint32_t)i;
+                cell_indices[i] = grid.position_to_cidx(positions[i]);
+            }
         }
         auto by_cell = [&](uint32_t a, uint32_t b) { return cell_indices[a] < cell_indices[b]; };
         // oracle extra (tiling-invariant mode, NOT the reference): ties inside a cell by persistent id (owner bit of the tile path masked)
@@ -403,6 +418,7 @@ struct CompactMortonCellGrid {  // :66-260
         auto by_cell_id = [&](uint32_t a, uint32_t b) {
             return cell_indices[a] != cell_indices[b] ? cell_indices[a] < cell_indices[b] : ((*tid)[a] & 0x7FFFFFFFu) < ((*tid)[b] & 0x7FFFFFFFu);
         };
+        PhaseTimer* pt_sort = new PhaseTimer(PH_SORT);
         if (tid && tid->size() == n) {
             std::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell_id);
         } else {
@@ -412,11 +428,15 @@ struct CompactMortonCellGrid {  // :66-260
             std::stable_sort(particle_indices.begin(), particle_indices.end(), by_cell);
 #endif
         }
-        apply_sorting(particle_indices, positions);  // :121-140
-        for (auto* a : attrs_vec) apply_sorting(particle_indices, *a);
-        for (auto* a : attrs_real) apply_sorting(particle_indices, *a);
-        for (auto* a : attrs_uint) apply_sorting(particle_indices, *a);
-
+        delete pt_sort;
+        {
+            PhaseTimer pt(PH_APPLY_SORTING);
+            apply_sorting(particle_indices, positions);  // :121-140
+            for (auto* a : attrs_vec) apply_sorting(particle_indices, *a);
+            for (auto* a : attrs_real) apply_sorting(particle_indices, *a);
+            for (auto* a : attrs_uint) apply_sorting(particle_indices, *a);
+        }
+        PhaseTimer pt_cells(PH_CELL_ARRAY);
         cells.clear();  // :142-165 (serial)
         uint16_t px = 0xFFFF, py = 0xFFFF;
         for (size_t pidx = 0; pidx < n; ++pidx) {
@@ -506,19 +526,36 @@ struct NeighborLists {  // :297-450
     std::vector<NeighborRange> ranges;
     std::vector<uint32_t> lists;  // AppendBuffer<u32> (appendbuffer.rs): capacity N*64, atomic bump
     std::atomic<size_t> size{0};
+    size_t entries = 0;  // list entries of the latest update (= size, except in the all_parallel variant, whose chunked reservations leave gaps)
     uint32_t overflow_flags = 0;  // bit0: a particle hit the 64 cap; bit1: the reference would have panicked (:373)
 
     void update(const GridProperties& grid, const CompactMortonCellGrid& dyn, const CompactMortonCellGrid& stat,
                 const std::vector<V2>& positions_dynamic, const std::vector<V2>& positions_static) {  // :312-397
+        PhaseTimer pt(PH_NEIGHBOR_LISTS);
         const size_t n = positions_dynamic.size();
         ranges.assign(n, NeighborRange{0, 0, 0});
-        if (lists.size() < n * MAX_NUM_NEIGHBORS) lists.resize(n * MAX_NUM_NEIGHBORS);  // :330
+        size_t room = n * MAX_NUM_NEIGHBORS;  // :330
+#ifdef ORC_OMP
+        if (g_all_parallel) room += (size_t)omp_get_max_threads() * 16384;  // (the all_parallel variant's chunk tails)
+#endif
+        if (lists.size() < room) lists.resize(room);
         size.store(0);
         const Real radius_sq = grid.radius * grid.radius;  // :331
         const long ncells = (long)dyn.cells.size() - 1;
         uint32_t flags = 0;
+        size_t total_entries = 0;
+        // all_parallel variant only (NOT the reference): a thread reserves list space 16 Ki entries at a time and hands it out to its own
+        // particles.  The reference's AppendBuffer takes ONE fetch_add per particle on a counter all threads share, and consecutive
+        // reservations — 32-40 bytes each — go to different threads, so every list line is written by several cores: on 128 threads that
+        // is 68 % of the step (cpu_baseline.phase_seconds_per_step: neighbor_lists 0.29 s of 0.43 s at 1 M; 8 threads: 0.06 s).
+        const size_t CHUNK = 16384;
 #ifdef ORC_OMP
-#pragma omp parallel for schedule(dynamic, 64) reduction(| : flags)  // :337 par_windows(2)
+#pragma omp parallel reduction(| : flags) reduction(+ : total_entries)
+#endif
+        {
+        size_t tl_pos = 0, tl_end = 0;
+#ifdef ORC_OMP
+#pragma omp for schedule(dynamic, 64)  // :337 par_windows(2)
 #endif
         for (long c = 0; c < ncells; ++c) {
             const MortonCell current_cell = dyn.cells[c];
@@ -570,11 +607,24 @@ struct NeighborLists {  // :297-450
                             if (distsq <= radius_sq && distsq > MIN_DISTANCE) flags |= 2;
                         }
                 }
-                const size_t start = size.fetch_add(count_total, std::memory_order_relaxed);  // appendbuffer.rs:48-61
+                size_t start;
+                if (g_all_parallel) {
+                    if (tl_pos + count_total > tl_end) {
+                        tl_pos = size.fetch_add(CHUNK, std::memory_order_relaxed);
+                        tl_end = tl_pos + CHUNK;
+                    }
+                    start = tl_pos;
+                    tl_pos += count_total;
+                } else {
+                    start = size.fetch_add(count_total, std::memory_order_relaxed);  // appendbuffer.rs:48-61
+                }
+                total_entries += count_total;
                 std::memcpy(lists.data() + start, neighbor_set, sizeof(uint32_t) * count_total);
                 ranges[i] = NeighborRange{(uint32_t)start, count_dynamic, count_total};  // :385-392
             }
         }
+        }
+        entries = total_entries;
         overflow_flags = flags;
     }
     inline const uint32_t* neighbors_dynamic(uint32_t p, uint32_t& n) const {  // :433
@@ -668,6 +718,7 @@ struct World {
     // :197-231
     template <class K>
     void update_densities(const K& kernel) {
+        PhaseTimer pt(PH_DENSITIES);
         const Real mass = particle_mass();
         const long n = (long)positions.size();
         const NeighborLists& nl = neighborhood.neighbor_lists;
@@ -772,6 +823,7 @@ struct DFSPHSolver {  // dfsph.rs:16-41
 
     // :68-97
     void compute_alpha_factors(const World& w) {
+        PhaseTimer pt(PH_ALPHA);
         const Real EPSILON = 1e-6f;
         const Real particle_mass = w.particle_mass();
         const NeighborLists& nl = w.neighborhood.neighbor_lists;
@@ -1015,6 +1067,7 @@ struct DFSPHSolver {  // dfsph.rs:16-41
             std::vector<V2>& accellerations = pool_accel;
             accellerations.resize(n);
             {  // :436-469 non-pressure forces
+                PhaseTimer pt(PH_NONPRESSURE);
                 const Real particle_mass = w.particle_mass();
                 const V2 non_pressure_forces = w.gravity * particle_mass;
                 const V2 non_pressure_accelleration = non_pressure_forces / particle_mass;
@@ -1037,6 +1090,7 @@ struct DFSPHSolver {  // dfsph.rs:16-41
                     accellerations[i] = a;
                 }
             }
+            PhaseTimer pt_vp(PH_VMAX_PREDICT);
             {  // :472-481 update timestep (serial)
                 Real max_velocity_sq = 0.0f;
                 if (g_all_parallel) {
@@ -1055,8 +1109,12 @@ struct DFSPHSolver {  // dfsph.rs:16-41
             ORC_PAR_IF_ALL
             for (long i = 0; i < (long)n; ++i) predicted_velocities[i] = w.velocities[i] + accellerations[i] * dt;  // :484-492 (serial)
         }
-        correct_density_error(dt, w, predicted_velocities, st);  // :496
+        {
+            PhaseTimer pt(PH_DENSITY_LOOP);
+            correct_density_error(dt, w, predicted_velocities, st);  // :496
+        }
         {                                                          // :499-510 advect (parallel)
+            PhaseTimer pt(PH_ADVECT);
 #ifdef ORC_OMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -1068,10 +1126,13 @@ struct DFSPHSolver {  // dfsph.rs:16-41
             w.update_neighborhood_datastructure({&predicted_velocities}, {});  // :512
         w.update_densities(kernel);                                        // :516
         compute_alpha_factors(w);                                          // :518
-        correct_divergence_error(dt, w, predicted_velocities, st);         // :521
+        {
+            PhaseTimer pt(PH_DIVERGENCE_LOOP);
+            correct_divergence_error(dt, w, predicted_velocities, st);  // :521
+        }
         std::swap(w.velocities, predicted_velocities);                     // :524
         st.neighbor_flags = w.neighborhood.neighbor_lists.overflow_flags;
-        st.neighbor_entries = w.neighborhood.neighbor_lists.size.load();
+        st.neighbor_entries = w.neighborhood.neighbor_lists.entries;
     }
 };
 
@@ -1149,7 +1210,7 @@ struct WCSPHSolver {  // wscsph.rs:14-23
         st.dt = dt;
         for (size_t i = 0; i < n; ++i) w.velocities[i] = w.velocities[i] + (0.5f * dt) * accellerations[i];  // leap frog 2
         st.neighbor_flags = w.neighborhood.neighbor_lists.overflow_flags;
-        st.neighbor_entries = w.neighborhood.neighbor_lists.size.load();
+        st.neighbor_entries = w.neighborhood.neighbor_lists.entries;
     }
 };
 
@@ -1248,6 +1309,14 @@ void orc_set_threads(int n) {
 #endif
 }
 void orc_set_all_parallel(int on) { g_all_parallel = on ? 1 : 0; }
+// per-phase seconds accumulated since the last reset, in OrcPhase order (oracle.py: PHASES); returns the number of phases
+int orc_phase_seconds(double* out, int n) {
+    for (int k = 0; k < n && k < PH_COUNT; ++k) out[k] = g_phase_seconds[k];
+    return PH_COUNT;
+}
+void orc_phase_reset() {
+    for (int k = 0; k < PH_COUNT; ++k) g_phase_seconds[k] = 0.0;
+}
 // what the OpenMP runtime this library is bound to really does with the threads (bench.py reports these, not environment strings)
 int orc_get_proc_bind() {
 #ifdef ORC_OMP
