@@ -39,6 +39,9 @@ __device__ __forceinline__ bool rect_has(const TileRect& r, uint32_t cx, uint32_
     return cx + halo >= r.x0 && cx < r.x1 + halo && cy + halo >= r.y0 && cy < r.y1 + halo;
 }
 __device__ __forceinline__ bool tile_owns(const Consts& K, float px, float py) {
+    // (single context: the rectangle is the whole u16 domain — a scalar test, and the twelve vector instructions of the cell + rectangle
+    // test are skipped in the four kernels that carry a reduction)
+    if (K.tile.x0 == 0u && K.tile.y0 == 0u && K.tile.x1 >= 65536u && K.tile.y1 >= 65536u) return true;
     uint32_t cx, cy;
     cell_of(K, make_float2(px, py), cx, cy);
     return rect_has(K.tile, cx, cy, 0u);
@@ -1246,7 +1249,8 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             on[u] = k0 + u < ct;
-            far[u] = on[u] && E[u] >= wlen_b;  // static neighbours (soff + boundary index) are never in the window
+            E[u] = on[u] ? E[u] : 0u;      // (a row past the end of the lane's list holds anything: make it an in-window slot, so that ...)
+            far[u] = E[u] >= wlen_b;       // (... this ONE compare is the ballot) static neighbours (soff + boundary index) are never in the window
             fm[u] = __builtin_amdgcn_ballot_w64(far[u]);
             if (FUSE) {
                 const uint32_t wb = min(E[u], wlen_b);  // slot wlen: pad
@@ -1268,9 +1272,10 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 if (cap != 0u && staged) {
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm[u], run));
                     run += (uint32_t)__popcll(fm[u]);
-                    if (far[u] && r < WAVE_REMOTE) {
+                    // (run <= WAVE_REMOTE — a scalar test — says that every line handed out so far exists: no per-lane bound test)
+                    if (far[u] && (run <= WAVE_REMOTE || r < WAVE_REMOTE)) {
                         rtab[r] = gb >> 3;
-                        lds_store_u32(ta + u * ROW_B, ((rbase + r) << 3) | 1u);
+                        lds_store_u32(ta + u * ROW_B, (r << 3) + ((rbase << 3) | 1u));
                     }
                 }
             }
