@@ -26,7 +26,8 @@
  *   INSPECTION — parity tests and tools, not on the hot path, may change with the data layout:
  *       sphx_update_neighborhood, sphx_update_densities, sphx_compute_alpha (the pieces benches/ drives), sphx_download_solver_state,
  *       sphx_download_neighbors, sphx_download_cells, sphx_grid_info, sphx_get_constants, sphx_last_flags, sphx_build_stats,
- *       sphx_multi_info, sphx_multi_tile_ctx, sphx_multi_set_layout / _set_grid_layout, sphx_profile_*, sphx_synchronize.
+ *       sphx_multi_info, sphx_multi_tile_ctx, sphx_multi_set_layout / _set_grid_layout, sphx_profile_*, sphx_synchronize,
+ *       sphx_set_tiling_invariant (a comparison mode: a run that does not depend on how the domain is tiled).
  *   INTERNAL — the seam between the tile loop (csrc/sphx_tiles.cpp) and a tile's context, exported so that the tests can drive the
  *       same sub-steps from the reference implementation of that loop (tests/tiles_reference.py); no stability promise:
  *       sphx_reserve, sphx_tile_*, sphx_sub_*, sphx_set_stream, sphx_shm_*.
@@ -43,7 +44,8 @@
 extern "C" {
 #endif
 
-#define SPHX_ABI_VERSION 3 /* 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
+#define SPHX_ABI_VERSION 4 /* 4: sphx_set_tiling_invariant
+                            * 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
                             * 3: sphx_comm_ops.abort, sphx_multi_info_t list statistics, sphx_shm_abort (and sphx_shm_open as a collective),
                             *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect, sphx_sub_predict_iteration, sphx_tile_band_packs,
                             *    sphx_multi_info_t.band_packs (was reserved) */
