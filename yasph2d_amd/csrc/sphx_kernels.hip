@@ -1542,7 +1542,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     const f32x2 d = f32x2{pj[u].x, pj[u].y} - f32x2{pi.x, pi.y};
                     const f32x2 q = d * d;
                     const float d2 = q.x + q.y;
-                    acc[u] = (u == 0u || rem > 8u * u) && d2 <= K.radius_sq && d2 > 1.0e-10f;  // (rem >= 8 inside the loop)
+                    // (bitwise, not short-circuit: three compares and two scalar ANDs in a straight line — with && the compiler nests
+                    // exec-mask branches around three instructions each)
+                    acc[u] = (bool)((int)(u == 0u || rem > 8u * u) & (int)(d2 <= K.radius_sq) & (int)(d2 > 1.0e-10f));  // (rem >= 8 inside the loop)
                 }
                 // every candidate is WRITTEN to the row the running address points at; a rejected one is overwritten by the next accepted
                 // one (the address has not moved), an accepted one is safe (the address moves past it).  The dump row absorbs the rest.
