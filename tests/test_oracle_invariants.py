@@ -208,3 +208,32 @@ def test_energy_only_dissipates_and_the_fluid_stays_in_its_container():
             d = o.densities()
             assert 100.0 <= d.mean() < 103.0
     assert energy() < 0.93 * e0, "viscosity and the impacts must have dissipated energy by now"
+
+
+def test_all_parallel_variant_of_the_cpu_baseline_computes_the_same_run():
+    """bench.py's cpu_baseline reports two variants of the OpenMP restatement: the reference-faithful one and `all_parallel` (the loops
+    the reference leaves serial run in parallel too and — round 4 — list space is reserved per thread instead of with one fetch_add per
+    particle on a shared counter, the reference's AppendBuffer).  Only the PLACE of a particle's list in the buffer differs (the
+    reference's start_index depends on the thread schedule anyway): positions, velocities, densities, iteration counts and the neighbour
+    lists themselves are identical, step by step."""
+    from oracle.oracle import lib
+
+    L = lib(omp=True)
+    pos, boundary = dam_break(1.5)
+    runs = []
+    for allpar in (0, 1):
+        L.orc_set_all_parallel(allpar)
+        o = Oracle(omp=True)
+        o.set_boundary(boundary)
+        o.set_particles(pos)
+        stats = [o.dfsph_step() for _ in range(80)]
+        c, s, l = o.neighbors()
+        runs.append((o.positions().copy(), o.velocities().copy(), o.densities().copy(), [(t["density_iterations"], t["divergence_iterations"]) for t in stats],
+                     c.copy(), l.copy(), stats[-1]["neighbor_entries"]))
+        del o
+    L.orc_set_all_parallel(0)
+    a, b = runs
+    for k in range(3):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32))
+    assert a[3] == b[3] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert a[6] == b[6] == int(a[4][:, 1].sum())
