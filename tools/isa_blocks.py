@@ -12,7 +12,7 @@ def main():
     dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l and l[0] == "_" and l.split(":")[0] and pat.search(l.split(":")[0]) and ":" in l)
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))  # (a kernel may hold several s_endpgm)
     body = lines[start:end + 1]
     if dump:
         open(dump, "w").write("\n".join(body))

@@ -32,12 +32,12 @@ constexpr uint32_t SCAN1_TILE = 256 * SCAN1_ITEMS;       // ... per workgroup
 #define SPHX_STAGE_ROWS 12
 #endif
 #ifndef SPHX_WIN_HALO
-#define SPHX_WIN_HALO 128
+#define SPHX_WIN_HALO 116  // (round 4: 116 instead of 128 — with the window of velocities the build then fits 20 KiB of LDS, eight workgroups per CU)
 #endif
 constexpr uint32_t STAGE_ROWS = SPHX_STAGE_ROWS;     // neighbour rows staged in LDS per wave before the coalesced row store
 constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions of [block_first - 128, block_last + 128] are staged in LDS (256: same speed at 6 instead of 7 workgroups per CU in the form that also stages velocities)
 #ifndef SPHX_LIST_HALO
-#define SPHX_LIST_HALO 128
+#define SPHX_LIST_HALO 116  // (= SPHX_WIN_HALO: the build's window of positions is the traversals' window)
 #endif
 // Neighbour lists are WORKGROUP-LOCAL: the traversal kernels stage the records of the sorted slots
 // [block_first - LIST_HALO, block_last + LIST_HALO] in LDS with coalesced loads; a list entry < LIST_WIN is a slot of that window,

@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                                         uint32_t* __restrict__ list, uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote,
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, bool scan, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
-                                        uint32_t (*tile)[STAGE_ROWS + 1][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
+                                        uint32_t (*tile)[STAGE_ROWS][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
                                         const float* swin, float warm_i) {
     constexpr bool FUSE = MODE >= 1;
     constexpr bool DIV = MODE == 2;
@@ -1400,10 +1400,11 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (DIV) block_residual_add(div_err, scal);
 }
 
-// MODE 2 holds a window of velocities next to the window of positions (21.1 KB of LDS, seven workgroups per CU instead of eight),
-// MODE 3 a window of warm-start values (19.1 KB, eight)
+// MODE 2 holds a window of velocities next to the window of positions: 20 464 bytes of LDS with a window halo of 116 slots and ONE dump
+// row for the four waves (round 4; 21.1 KB and seven workgroups per CU before) — eight workgroups per CU, 54 registers;
+// MODE 3 a window of warm-start values (18.5 KB, eight)
 #ifndef SPHX_NB_WAVES_M2
-#define SPHX_NB_WAVES_M2 7
+#define SPHX_NB_WAVES_M2 8
 #endif
 #ifndef SPHX_NB_WAVES_M3
 #define SPHX_NB_WAVES_M3 8
@@ -1418,13 +1419,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     // (one object, the window first: at LDS offset 0 the four slots of a trip are one clamped base register + immediate offsets)
     struct Smem {
         float2 win[WIN_SLOTS + WIN_PAD];       // positions of the sorted particles around this workgroup's 256 (+ pad slots)
-        uint32_t tile[4][STAGE_ROWS + 1][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave (+ a dump row for rejected candidates)
+        uint32_t tile[4][STAGE_ROWS][64];  // neighbour rows 0..STAGE_ROWS-1 of each wave
+        uint32_t dump[64];                 // one row for all four waves: where the candidates of a lane whose staged rows are full go (nobody reads it)
         float2 vwin[MODE == 2 ? WIN_SLOTS + WIN_PAD : 1];  // MODE 2: their velocities
         float swin[MODE == 3 ? WIN_SLOTS + WIN_PAD : 1];   // MODE 3: their warm-start stiffness
     };
     __shared__ Smem sm;
     float2* const win = sm.win;
-    uint32_t (*const tile)[STAGE_ROWS + 1][64] = sm.tile;
+    uint32_t (*const tile)[STAGE_ROWS][64] = sm.tile;
     float2* const vwin = sm.vwin;
     float* const swin = sm.swin;
     const uint32_t i = xcd_bid() * 256 + threadIdx.x;
@@ -1491,7 +1493,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         // accepted candidate.  t_dump: the dump row (row STAGE_ROWS); t_fast: while no lane of the wavefront is past it, the four
         // candidates of a trip land in staged rows (or, rejected, in the dump row) whatever is accepted: no clamp, no spill test.
         const uint32_t t_base = lds_addr(&tile[w][0][lane]);
-        const uint32_t t_dump = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;
+        const uint32_t t_end = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;  // t_end: one past the lane's last staged row
+        const uint32_t t_dump = lds_addr(&sm.dump[lane]);
         uint32_t ta = t_base;
         const uint32_t far_lim = wlen_b > 24u ? wlen_b - 24u : 0u;  // a trip starting at or beyond this byte offset (or below the window) leaves the window
         const uint32_t nw0b = 0u - w0b;
@@ -1557,8 +1560,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     for (uint32_t u = 0; u < W; ++u) lds_store_u32(a[u], ab + 8u * u);
                 } else {
 #pragma unroll
-                    for (uint32_t u = 0; u < W; ++u) lds_store_u32(min(a[u], t_dump), ab + 8u * u);
-                    if (a[W] > t_dump) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
+                    for (uint32_t u = 0; u < W; ++u) lds_store_u32(a[u] < t_end ? a[u] : t_dump, ab + 8u * u);
+                    if (a[W] > t_end) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
 #pragma unroll
                         for (uint32_t u = 0; u < W; ++u) {
                             const uint32_t row = (a[u] - t_base) / ROW_B;
