@@ -22,6 +22,14 @@ __device__ __forceinline__ uint32_t part1by1(uint32_t x) {  // morton.rs:38-45 (
 }
 __device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) { return (part1by1(y) << 1) | part1by1(x); }  // morton.rs:49-51
 
+// the low 6 bits of a cell coordinate spread to the even bit positions: the x half of a cell's 12-bit Morton code inside its 64x64 block
+__device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2,4,6,8,10
+    v &= 63u;
+    v = (v | (v << 4)) & 0x30Fu;
+    v = (v | (v << 2)) & 0x333u;
+    v = (v | (v << 1)) & 0x555u;
+    return v;
+}
 // Rust `f32 as u16` (saturating, NaN -> 0), neighborhood_search.rs:55-56
 __device__ __forceinline__ uint32_t sat_u16(float v) {
     v = fminf(fmaxf(v, 0.0f), 65535.0f);
@@ -560,9 +568,9 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
         cell_of(K, p, cx, cy);
         const bool dropped = p.x != p.x;  // tile mode marks particles that left the tile with a NaN position: they get no cell
         uint32_t f = 0;
-        const uint32_t code = morton2(cx, cy);
+        const uint32_t code = spread6(cx) | (spread6(cy) << 1);  // = morton2(cx, cy) & (BLOCK_CELLS - 1): only the place inside the block is needed
         const uint32_t entry = dropped ? EMPTY : dir_entry(g, cx, cy, ahead);
-        idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
+        idx = entry == EMPTY ? EMPTY : (entry & ~DIR_FLAGS) + code;
         if (!dropped) {
             if (entry == EMPTY) {
                 if (ring) {
@@ -1029,13 +1037,6 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
 // Morton order, cells inside a block by the low 12 bits of their code), so sorting the SLOTS sorts the cells by Morton code —
 // no 32-bit codes, no de-interleaving of block coordinates.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit
 // positions.
-__device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> bits 0,2,4,6,8,10
-    v &= 63u;
-    v = (v | (v << 4)) & 0x30Fu;
-    v = (v | (v << 2)) & 0x333u;
-    v = (v | (v << 1)) & 0x555u;
-    return v;
-}
 // Round 4: the look-ups go through the NbGrid form of the directory (sphx_internal.hpp), in which no entry is special: a block that
 // is not covered points at the all-empty null block behind the table, block coordinates outside the directory's rectangle are
 // clamped into it (what is found there lies >= 60 cells away and fails the distance test; it never aliases a cell of the box
@@ -1323,15 +1324,16 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     float div_err = 0.0f;
     if (FUSE && live) {
         const float gsx = gs2.x, gsy = gs2.y, wsx = ws.x, wsy = ws.y;
-        density[i] = fmaxf(rho, K.rho0);                                // fluidparticleworld.rs:229
+        const uint32_t i4 = i * 4u;  // (scalar base + 32-bit lane offset: contexts hold < 2^28 slots)
+        *(float*)((char*)density + i4) = fmaxf(rho, K.rho0);            // fluidparticleworld.rs:229
         const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
-        alpha[i] = alpha_i;
+        *(float*)((char*)alpha + i4) = alpha_i;
         if (DIV) {
             const float e = ct < 9u ? 0.0f : fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:261, :277-278
-            dv.kbuf[i] = e * alpha_i;  // (the warm-start stiffness is not zeroed here: the loop's first correction starts it from zero)
+            *(float*)((char*)dv.kbuf + i4) = e * alpha_i;  // (the warm-start stiffness is not zeroed here: the loop's first correction starts it from zero)
             div_err = tile_owns(K, pi.x, pi.y) ? e : 0.0f;
         }
-        if (WARM) dv.velw[i] = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
+        if (WARM) *(float2*)((char*)dv.velw + 2u * i4) = make_float2(vi.x - wsx * K.mass, vi.y - wsy * K.mass);  // dfsph.rs:342
     }
     // ---- list rows ----------------------------------------------------------------------------------------------------------------
     uint32_t spill_rem = 0, spill_before = 0;
