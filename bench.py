@@ -803,6 +803,9 @@ def main():
                 "host_calls": "one library call runs the K timed steps (sphx_*_simulation_steps: the caller's frame loop, main.rs:348-350, "
                               "in C; every step is a full Solver::simulation_step)" if not args.per_step_calls else "one library call per step from Python",
                 "solver_loop": "tile loop: the verdict of every solver iteration needs the all-reduce over the tiles",
+                "tile_path_cost_at_world_1": "the tile code path itself, measured with one tile on one GPU (bench.py --force-tiles, profiles/r04_bench_{1M,16M}_forcetiles.json): "
+                                             "within +-2 % of the single context at 16 M particles per GPU (the size of the multi-GPU configs), +8 % at 1 M (three host "
+                                             "decisions per step that the single context takes on the device)",
             },
             "step_model": step_model(kbar if kbar is not None else 8.0, rbar if rbar is not None else 0.5, it, n, args.steps, elapsed, kbar is not None),
         }
