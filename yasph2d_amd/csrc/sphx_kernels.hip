@@ -1082,7 +1082,8 @@ __device__ __forceinline__ void ranges9n(const NbGrid& g, const uint32_t (&slot)
     }
 }
 
-// 8 waves per SIMD = 8 workgroups per CU: the staged rows (13 KiB) + the window (6 KiB) keep a workgroup below 20 KiB of the CU's
+// 8 waves per SIMD = 8 workgroups per CU: the staged rows (12 KiB) + the window (4 KiB; two of them in the form that also stages
+// velocities) keep a workgroup below 20 KiB of the CU's
 // 160 KiB, and the kernel fits the register budget of 64.  At 1 M particles the 3 906 workgroups then fit into two "rounds" of the
 // chip.
 // Round 1-2: the kernel was bound by the LENGTH of its chain of dependent memory round trips — own position + window + directory +
@@ -1492,8 +1493,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         SPHX_STAMP(1)
 #ifndef SPHX_ABL_NOLOOP
         // the list row the next accepted candidate goes to, as an LDS byte address (row ct of this lane): it moves by one row per
-        // accepted candidate.  t_dump: the dump row (row STAGE_ROWS); t_fast: while no lane of the wavefront is past it, the four
-        // candidates of a trip land in staged rows (or, rejected, in the dump row) whatever is accepted: no clamp, no spill test.
+        // accepted candidate.  t_dump: the dump row (one for the workgroup: what is written there is never read); t_fast: while no
+        // lane of the wavefront is past it, the four candidates of a trip land in staged rows whatever is accepted: no clamp, no spill test.
         const uint32_t t_base = lds_addr(&tile[w][0][lane]);
         const uint32_t t_end = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;  // t_end: one past the lane's last staged row
         const uint32_t t_dump = lds_addr(&sm.dump[lane]);
