@@ -94,7 +94,14 @@ struct NbView {
     const uint16_t* counts;
     const uint32_t* wave;
     const uint32_t* remote;
+    // round 4: the upper 64 lines of a wavefront's out-of-window table are only fetched when the wavefront uses more than 64 (bit 14 of
+    // its particles' count words says so: known from a load every walk makes first anyway, and by the time the branch waits for it
+    // everything else the walk needs has been requested).  4 bytes per particle and walk less: the traversals -1...-4 % at 16 M, nothing
+    // lost at 1 M (same-box A/B, profiles/r04_experiments/lazy_table_ab.txt; round 3 had tried the per-wavefront word as the condition —
+    // a scalar load of its own — and lost 3 % at 1 M).  SPHX_LAZY_TABLE=0 turns it off.
+    uint32_t lazy_hi;
 };
+constexpr uint32_t COUNT_MANY_LINES = 1u << 14;  // count word: the wavefront's table holds more than 64 lines
 // positions + velocities of the [N|B] arrays as one read view (sphx_kernels.hip: ldpv)
 struct PVr {
     const float2* pos;
@@ -351,7 +358,8 @@ struct sphx_ctx {
     // WCSPH: number of leading slots of accel[] that hold the previous step's accelerations (the rest count as zero)
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;
-    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote}; }
+    int lazy_table = 1;  // SPHX_LAZY_TABLE=0 (A/B runs): every walk fetches all 128 table lines of its wavefront
+    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table}; }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;

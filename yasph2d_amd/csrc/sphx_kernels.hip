@@ -1346,7 +1346,8 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     }
     const uint32_t rtot = run + spill_rem;
     const bool wide = cap == 0u || rtot > cap;
-    if (live) counts[i] = (uint16_t)(cd | (ct << 7));  // NeighborRange, neighborhood_search.rs:269-273
+    // NeighborRange, neighborhood_search.rs:269-273 (+ bit 14: this wavefront's table holds more than 64 lines, NbView::lazy_hi)
+    if (live) counts[i] = (uint16_t)(cd | (ct << 7) | ((!wide && rtot > 64u) ? COUNT_MANY_LINES : 0u));
     if (lane == 0) wave[i >> 6] = (wide ? 0x80000000u : rtot);  // the wavefront's list format + table lines in use
     if (wide) {
         // 32-bit rows; entries past the staged rows already sit at their 32-bit address.  An entry that phase 2 has turned into a code
@@ -1643,8 +1644,9 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     // The table lines are requested before anything else: the addresses of the out-of-window records come from them (the only
     // two-step chain of the staging), and loads return in order — behind the list words they would arrive with the last of those.
     h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
-#pragma unroll
-    for (uint32_t u = 0; u < WAVE_REMOTE / 64; ++u) h.g[u] = active ? h.rtab[(threadIdx.x & 63u) + u * 64u] : 0u;
+    static_assert(WAVE_REMOTE == 128, "two halves of 64 lines");
+    h.g[0] = active ? h.rtab[threadIdx.x & 63u] : 0u;
+    if (!nb.lazy_hi) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
     // clamped, not predicated: behind a branch the compiler unpacks the word INSIDE it and waits for the load there — a whole
     // round trip before the first of the other loads was even requested
     const uint32_t craw = nb.counts[min(i, n ? n - 1u : 0u)];
@@ -1662,6 +1664,10 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
     // (a workgroup past the last particle — the grid is rounded up to a multiple of eight — stages slot 0: its clamped loads must
     // not reach past the [N|B] arrays)
+    if (nb.lazy_hi) {  // (everything else a walk needs has been requested by now: the wait for the count word delays nothing but this)
+        h.g[1] = 0u;
+        if (__any((c & COUNT_MANY_LINES) != 0u)) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
+    }
     h.lw0 = active && b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
     return h;
