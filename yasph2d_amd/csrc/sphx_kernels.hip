@@ -1119,6 +1119,7 @@ typedef __attribute__((address_space(3))) const f32x4_a8 lds_cf4a8;  // two cons
 constexpr uint32_t WIN_SLOTS = 256 + 2 * WIN_HALO;
 constexpr uint32_t WIN_PAD = 4;  // a trip of the candidate scan reads four consecutive slots from a clamped base: pad slots behind the window
 constexpr uint32_t ROW_B = 256;  // bytes between two rows of a wavefront's staged list
+constexpr uint32_t SUBROW_B = 256;  // bytes of a narrow sub-row in global memory: three 10-bit entries in one 32-bit word per lane
 // The window of positions the build stages IS the window the traversal kernels stage (NbHead): a staged entry that lies inside it is
 // its own narrow list entry (E >> 3), one outside it needs a line of the out-of-window table — the same test the density pass makes
 // to decide whether the neighbour's record is in LDS.
@@ -1362,23 +1363,23 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     } else {
         // three rows = one 32-bit word per lane, half of the 8-byte word the lane owns in a row group (rows >= m of the last word hold
         // don't-care values: traversals stop at the count)
-        const uint32_t lane8 = lane * 8u;
+        const uint32_t lane4 = lane * 4u;
 #pragma unroll
         for (uint32_t k0 = 0; k0 < STAGE_ROWS; k0 += 3u) {
             if (k0 >= m) break;  // (scalar)
             const uint32_t v0 = lds_load_u32(t_row0 + k0 * ROW_B), v1 = lds_load_u32(t_row0 + (k0 + 1u) * ROW_B), v2 = lds_load_u32(t_row0 + (k0 + 2u) * ROW_B);
-            *(uint32_t*)(slice + ((k0 / GROUP) * 512u + ((k0 / 3u) & 1u) * 4u + lane8)) = pack3_staged(v0, v1, v2);
+            *(uint32_t*)(slice + ((k0 / 3u) * SUBROW_B + lane4)) = pack3_staged(v0, v1, v2);
         }
         if (spill) {
             // Entries past the staged rows sit in global memory as 32-bit slots (written by phase 1 at their wide address: row k at byte
-            // 256 k + 4 lane of the slice).  Their narrow home — the 8-byte word of group q = k / 6 at byte 512 q + 8 lane — lies below
-            // every wide row >= 6 q (q >= 2 here), and the whole wavefront reads the six wide rows of a group before it writes the group's
-            // word: rewriting in ascending q never overwrites an entry still to be read.
+            // 256 k + 4 lane of the slice).  Their narrow home — the 32-bit word of sub-row q = k / 3 at byte 256 q + 4 lane — is the place
+            // of wide row q, which lies below every wide row >= 3 q (q >= 4 here), and the whole wavefront reads the three wide rows of a
+            // sub-row before it writes the sub-row's word: rewriting in ascending q never overwrites an entry still to be read.
             uint32_t r = run + spill_before;
-            for (uint32_t k0 = STAGE_ROWS; k0 < mct; k0 += GROUP) {
-                uint32_t sl[GROUP];
+            for (uint32_t k0 = STAGE_ROWS; k0 < mct; k0 += 3u) {
+                uint32_t sl[3];
 #pragma unroll
-                for (uint32_t u = 0; u < GROUP; ++u) {
+                for (uint32_t u = 0; u < 3u; ++u) {
                     const bool on = k0 + u < ct;
                     const uint32_t g = on ? list[ell_index(i, k0 + u)] : w0;
                     const bool rem = on && g - w0 >= wlen;
@@ -1390,7 +1391,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 // only per lane, so make it so for the wavefront)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (k0 < ct) *(uint2*)(slice + ((k0 / GROUP) * 512u + lane * 8u)) = make_uint2(pack3(sl[0], sl[1], sl[2]), pack3(sl[3], sl[4], sl[5]));
+                if (k0 < ct) *(uint32_t*)(slice + ((k0 / 3u) * SUBROW_B + lane * 4u)) = pack3(sl[0], sl[1], sl[2]);
             }
         }
     }
@@ -1610,9 +1611,14 @@ constexpr uint32_t STAGE_SLOTS = next_pow2(LIST_WIN + REMOTE_CAP);  // LDS stagi
 // A narrow list entry is a slot of that staging area: TEN bits (the window and the out-of-window table together have 1024 slots).
 // Three entries to a 32-bit word, six to the 8-byte word a lane owns in a row of its wavefront's slice: 1.33 bytes per entry
 // (round 2: 16-bit entries, four to the word).
-static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % GROUP == 0 && LIST_WIN + REMOTE_CAP <= (1u << ENTRY_BITS) && STAGE_SLOTS == (1u << ENTRY_BITS),
+static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % 3 == 0 && LIST_WIN + REMOTE_CAP <= (1u << ENTRY_BITS) && STAGE_SLOTS == (1u << ENTRY_BITS),
               "staging loops / packed groups / 10-bit slots");
-constexpr uint32_t NB_G0 = STAGE_ROWS / GROUP;  // packed 6-entry groups every traversal loads up front (12 entries; the rest on demand)
+// Narrow layout of a wave's slice (round 4): SUB-ROWS of three entries — one 32-bit word per lane, 256 bytes per wavefront; entries
+// 3q .. 3q+2 of a lane sit at q * 256 + lane * 4.  A wavefront whose longest list has 8 entries moves three sub-rows (768 bytes);
+// round 3 kept six entries in an 8-byte word per lane, i.e. 1 024 bytes for the same wavefront (lines are fetched whole: the unused
+// upper halves came along).  The first NB_S0 sub-rows are requested up front, the fourth when some lane of the wavefront has more than
+// nine entries (known from the count word, like the upper half of the table), the rest on demand.
+constexpr uint32_t NB_S0 = 3, NB_S1 = STAGE_ROWS / 3;
 
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1630,7 +1636,7 @@ struct NbHead {
     uint32_t cd, ct;      // NeighborRange: dynamic / total neighbours
     uint32_t R;           // entries of this wavefront's quarter of the out-of-window table (0 when wide)
     bool wide;            // this wavefront's lists hold 32-bit global slots (wave-uniform)
-    uint2 e[NB_G0];       // entries 0..11, six 10-bit staging slots per word pair (narrow format)
+    uint32_t e[NB_S1];    // entries 0..11, three 10-bit staging slots per word (narrow format)
     const char* rows;     // this wave's 16 KiB slice of the list buffer
     uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
@@ -1661,12 +1667,17 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     h.lane = i & 63u;
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
 #pragma unroll
-    for (uint32_t q = 0; q < NB_G0; ++q) h.e[q] = i < n ? *(const uint2*)(h.rows + q * 512u + h.lane * 8u) : make_uint2(0u, 0u);
+    for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
     // (a workgroup past the last particle — the grid is rounded up to a multiple of eight — stages slot 0: its clamped loads must
     // not reach past the [N|B] arrays)
     if (nb.lazy_hi) {  // (everything else a walk needs has been requested by now: the wait for the count word delays nothing but this)
         h.g[1] = 0u;
         if (__any((c & COUNT_MANY_LINES) != 0u)) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
+    }
+#pragma unroll
+    for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9..11: only for a wavefront that has them
+        h.e[q] = 0u;
+        if (__any(h.ct > 3u * q)) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
     }
     h.lw0 = active && b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
@@ -1757,17 +1768,11 @@ __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& 
             if (__any(lim > k + 2u)) consume(r[2], k + 2u);
         };
 #pragma unroll
-        for (uint32_t q = 0; q < NB_G0; ++q) {
-            if (!__any(lim > GROUP * q)) return;
-            triple(h.e[q].x, GROUP * q);
-            if (!__any(lim > GROUP * q + 3u)) return;
-            triple(h.e[q].y, GROUP * q + 3u);
+        for (uint32_t q = 0; q < NB_S1; ++q) {
+            if (!__any(lim > 3u * q)) return;
+            triple(h.e[q], 3u * q);
         }
-        for (uint32_t q = NB_G0; __any(lim > GROUP * q); ++q) {
-            const uint2 e = *(const uint2*)(h.rows + q * 512u + h.lane * 8u);
-            triple(e.x, GROUP * q);
-            if (__any(lim > GROUP * q + 3u)) triple(e.y, GROUP * q + 3u);
-        }
+        for (uint32_t q = NB_S1; __any(lim > 3u * q); ++q) triple(*(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u), 3u * q);
     } else {
         // round-1 path: 32-bit rows, records gathered from global memory, batches of NB_BATCH with the index loads of the next
         // batch issued behind the gathers of the current one
@@ -2504,7 +2509,7 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
         if (h.wide) {
             g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
         } else {
-            const uint32_t word = *(const uint32_t*)(h.rows + (k / GROUP) * 512u + h.lane * 8u + ((k % GROUP) / 3u) * 4u);
+            const uint32_t word = *(const uint32_t*)(h.rows + (k / 3u) * SUBROW_B + h.lane * 4u);
             const uint32_t slot = (word >> (ENTRY_BITS * (k % 3u))) & ENTRY_MASK;
             g = slot < LIST_WIN ? h.lw0 + slot : nb.remote[(size_t)(i >> 8) * REMOTE_CAP + (slot - LIST_WIN)];
         }
