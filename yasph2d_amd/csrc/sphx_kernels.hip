@@ -1252,9 +1252,9 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             on[u] = k0 + u < ct;
-            E[u] = on[u] ? E[u] : 0u;      // (a row past the end of the lane's list holds anything: make it an in-window slot, so that ...)
-            far[u] = E[u] >= wlen_b;       // (... this ONE compare is the ballot) static neighbours (soff + boundary index) are never in the window
-            fm[u] = __builtin_amdgcn_ballot_w64(far[u]);
+            // (two ballots of plain compares and a scalar AND: the ballot of a conjunction costs a select and a second compare)
+            fm[u] = __builtin_amdgcn_ballot_w64(on[u]) & __builtin_amdgcn_ballot_w64(E[u] >= wlen_b);
+            far[u] = on[u] && E[u] >= wlen_b;  // static neighbours (soff + boundary index) are never in the window
             if (FUSE) {
                 const uint32_t wb = min(E[u], wlen_b);  // slot wlen: pad
                 rj[u] = lds_read_f2((const float2*)((const char*)win + wb));
