@@ -100,6 +100,10 @@ struct NbView {
     // lost at 1 M (same-box A/B, profiles/r04_experiments/lazy_table_ab.txt; round 3 had tried the per-wavefront word as the condition —
     // a scalar load of its own — and lost 3 % at 1 M).  SPHX_LAZY_TABLE=0 turns it off.
     uint32_t lazy_hi;
+    // round 4: list words and table lines are read exactly once per walk; a context whose lists do not fit the caches anyway (>= 4 M
+    // particles) reads them with the nontemporal hint (-1 % at 16 M; at 1 M, where the lists of one walk are still in the Infinity
+    // Cache for the next, the hint costs 1-5 %: profiles/r04_experiments/scan_touched_tiles.txt).  SPHX_STREAM_LISTS=0/1 overrides.
+    uint32_t stream;
 };
 constexpr uint32_t COUNT_MANY_LINES = 1u << 14;  // count word: the wavefront's table holds more than 64 lines
 // positions + velocities of the [N|B] arrays as one read view (sphx_kernels.hip: ldpv)
@@ -359,7 +363,10 @@ struct sphx_ctx {
     uint32_t wcsph_n = 0;
     bool in_wcsph = false;
     int lazy_table = 1;  // SPHX_LAZY_TABLE=0 (A/B runs): every walk fetches all 128 table lines of its wavefront
-    sphx::NbView nbv() const { return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table}; }
+    int stream_lists = -1;  // SPHX_STREAM_LISTS=0/1 (A/B runs); -1: by size
+    sphx::NbView nbv() const {
+        return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table, stream_lists < 0 ? (N >= 4000000u ? 1u : 0u) : (uint32_t)stream_lists};
+    }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;
     uint32_t scan_partials_cap = 0;

@@ -1651,7 +1651,7 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     // two-step chain of the staging), and loads return in order — behind the list words they would arrive with the last of those.
     h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
     static_assert(WAVE_REMOTE == 128, "two halves of 64 lines");
-    h.g[0] = active ? h.rtab[threadIdx.x & 63u] : 0u;
+    h.g[0] = active ? (nb.stream ? __builtin_nontemporal_load(&h.rtab[threadIdx.x & 63u]) : h.rtab[threadIdx.x & 63u]) : 0u;
     if (!nb.lazy_hi) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
     // clamped, not predicated: behind a branch the compiler unpacks the word INSIDE it and waits for the load there — a whole
     // round trip before the first of the other loads was even requested
@@ -1666,8 +1666,14 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     h.R = h.wide ? 0u : min(ww & 0x3ffu, WAVE_REMOTE);
     h.lane = i & 63u;
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
+    // (NbView::stream: a context too large for the caches reads the words a walk uses exactly once with the streaming hint)
+    if (nb.stream) {
 #pragma unroll
-    for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
+        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? __builtin_nontemporal_load((const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u)) : 0u;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
+    }
     // (a workgroup past the last particle — the grid is rounded up to a multiple of eight — stages slot 0: its clamped loads must
     // not reach past the [N|B] arrays)
     if (nb.lazy_hi) {  // (everything else a walk needs has been requested by now: the wait for the count word delays nothing but this)
