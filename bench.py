@@ -239,6 +239,9 @@ def main():
                                                              "the host mirror's one call per step (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run-scene", action="store_true",
+                    help="with --dry-run: every rank also builds the GLOBAL scene on its host, like a real run does before it cuts its tile "
+                         "(times the set-up of an N-rank run without a GPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test: ranks rendezvous (gloo), barrier, all-reduce and print the line with value = null; no GPU, no compute")
     args = ap.parse_args()
@@ -281,6 +284,20 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        scene_s, scene_n = None, None
+        if args.dry_run_scene:
+            import yasph2d_amd as y  # host-side scene generator only (no GPU call)
+
+            ts = time.perf_counter()
+            wsc = y.FluidParticleWorld()
+            wsc.reset_fluid(float(np.sqrt(args.particles * world / 4050.0)))
+            scene_n = len(wsc.positions)
+            scene_s = time.perf_counter() - ts
+            del wsc
+            ts_t = torch.tensor([scene_s], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(ts_t, op=dist.ReduceOp.MAX)
+            scene_s = float(ts_t.item())
         ipc_env = [os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")]
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,6 +315,8 @@ def main():
                                              "config": {"workload": "dry run: no compute; would run " + dry_workload(args.particles, world),
                                                         "particles_per_gpu": args.particles,
                                                         "HSA_ENABLE_IPC_MODE_LEGACY_per_rank": ipc_env,
+                                                        "scene_build_seconds_max_over_ranks": scene_s, "scene_particles": scene_n,
+                                                        "seconds_since_process_start": time.perf_counter() - t_process_start,
                                                         "launcher": "external (RANK was in the environment)" if launched else "bench.py's own child"}}) + "\n").encode())
         if world > 1:
             dist.barrier()

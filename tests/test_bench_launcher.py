@@ -75,6 +75,15 @@ def test_ranks_started_by_an_external_launcher_get_the_dmabuf_ipc_variable():
     assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY_per_rank"] == ["0", "0"]
 
 
+def test_dry_run_can_time_the_scene_build_of_every_rank():
+    """`--dry-run --dry-run-scene`: every rank builds the GLOBAL scene like a real N-rank run does before it cuts its tile; the line carries
+    the slowest rank's seconds (what DESIGN.md section 7 quotes for 8 ranks x 128 M particles)."""
+    rc, out, err = run(["--gpus", "2", "--dry-run", "--dry-run-scene", "--particles", "20000"])
+    assert rc == 0, err
+    c = json.loads([ln for ln in out.splitlines() if ln.strip()][-1])["config"]
+    assert 39_000 < c["scene_particles"] < 41_000 and c["scene_build_seconds_max_over_ranks"] > 0.0
+
+
 def test_world_size_must_match_gpus():
     rc, out, err = run(["--gpus", "2", "--dry-run"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert rc != 0 and out.strip() == ""
