@@ -84,6 +84,11 @@ struct Consts {
     // a workgroup with at most remote_cap out-of-window neighbour entries stores workgroup-local 10-bit lists (<= REMOTE_CAP;
     // 0 forces 32-bit global lists)
     uint32_t remote_cap;
+    // 1: the walks may use their FAST forms (sphx_kernels.hip, sqrt_dist): the lists belong to the positions (raised by the neighbour
+    // build, dropped by an upload) and fl(r * w_hinv) <= 1 for every r a list can hold (r <= h: checked by the host for this h), i.e.
+    // the min(q, 1) of WendlandQuinticC2::evaluate / gradient (wendland_quintic_c2.rs:35,43) is the identity and the sqrt's argument
+    // is far from the ends of the exponent range
+    uint32_t q_noclamp;
 };
 
 // wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 = NeighborRange
@@ -268,6 +273,7 @@ struct sphx_ctx {
     uint32_t B = 0, capB = 0;  // boundary particles
     uint32_t cached_n = 0;     // alpha_values.len() of the reference (dfsph.rs:419)
     bool uploaded = false, boundary_changed = true, tails_dirty = true, in_step = false;
+    uint32_t fast_walk_ok = 0;  // this smoothing length allows the FAST walks (sqrt_dist); K.q_noclamp = fast_walk_ok while the lists are fresh
     uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
     float step_dt_prev = 0, step_vmax = 0;
     uint32_t step_flags = 0;

@@ -98,18 +98,40 @@ __device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uin
     return off == EMPTY ? EMPTY : (off & ~DIR_FLAGS) + (code & (BLOCK_CELLS - 1u));
 }
 
-// Correctly rounded sqrt of a squared neighbour distance.  Every list entry passed `d2 > 1e-10` when the list was built and the
-// positions have not moved since, so the argument is a normal number far above 2^-96: the compiler's sqrtf expansion (16
-// instructions) spends 7 of them on rescaling tiny arguments and passing 0/inf/nan through.  What is left is its own correction
-// of v_sqrt_f32 (1 ulp): try one ulp down and one ulp up with exact fma residuals.  (0, inf and nan still come out as sqrtf
-// gives them: every compare below is false for them.)
+// Correctly rounded sqrt of a squared neighbour distance, and the clamp of q = r / h: the FAST forms of a walk.
+// FAST (Consts::q_noclamp; wave-uniform, chosen by the host): the lists the walk reads were built from the positions it reads — every
+// entry passed 1e-10 < d2 <= fl(h h) — and fl(h * w_hinv) <= 1.  Then
+//  * the argument of the sqrt is a normal number far from both ends of the exponent range.  The compiler's sqrtf (16 instructions)
+//    spends 7 of them on rescaling tiny arguments and passing 0/inf/nan through; rounds 1-4 kept its correction of v_sqrt_f32 (1 ulp:
+//    try one ulp down and one up with exact fma residuals and select — sqrt, two integer adds, two fma, two compares, two selects: 9
+//    instructions, 36 cycles at this part's instruction costs: sqrt 8, add 2, the others 4, tools/valu_issue_bench.hip).  Round 5:
+//    the compiler's OTHER correctly rounded form (the one it uses where v_sqrt_f32 is not trusted) without the rescaling: y = rsq(x);
+//    {s, h} = {x y, y / 2}; one coupled Newton step on both (its two updates in ONE packed fma), one residual step — 7 instructions,
+//    28 cycles, no compares.  Exact for EVERY float in [2^-100, 2^100]: all 1 677 721 601 of them checked against sqrtf on the device
+//    and a sample against the host (tools/sqrt_exhaustive.hip, profiles/r05_sqrt_exhaustive.txt; below 2^-102 it goes wrong, where
+//    the old form went wrong too; 0, inf and nan come out as nan);
+//  * min(q, 1) (wendland_quintic_c2.rs:35,43) is the identity: r = sqrt(d2) <= sqrt(fl(h h)) = h (both correctly rounded, monotone;
+//    the host checks sqrt(fl(h h)) == h), so q = fl(r * w_hinv) <= fl(h * w_hinv) <= 1 (checked by the host; 1.0 exactly for
+//    h = 0.02).  v_min_f32 is a 4-cycle instruction.
+// Not FAST: positions were replaced behind the lists' back (sphx_upload with an unchanged particle count: the reference walks its
+// old lists over the new positions too, dfsph.rs:419) or h fails the host's checks: plain sqrtf and the clamp, whatever d2 is.
+template <bool FAST>
 __device__ __forceinline__ float sqrt_dist(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
-    s = vp <= 0.0f ? sd : s;
-    return vs > 0.0f ? su : s;
+    if (!FAST) return sqrtf(x);
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const float y = __builtin_amdgcn_rsqf(x);
+    // (two plain multiplies — 2-cycle class — into a register pair; as ONE packed multiply of {x, 1/2} by {y, y} the constant has to be
+    // moved into the pair's upper half for every neighbour: 2 + 4 cycles instead of 2 + 2)
+    float s0 = x * y, h0 = 0.5f * y;
+    asm("" : "+v"(s0), "+v"(h0));
+    f32x2_ sh = f32x2_{s0, h0};                             // {s, h} = {x y, y / 2}
+    const float e = __builtin_fmaf(-sh.y, sh.x, 0.5f);      // 1/2 - h s
+    sh = __builtin_elementwise_fma(sh, f32x2_{e, e}, sh);   // s += s e, h += h e
+    const float d = __builtin_fmaf(-sh.x, sh.x, x);         // x - s^2
+    return __builtin_fmaf(d, sh.y, sh.x);
 }
+template <bool FAST>
+__device__ __forceinline__ float clamp_q(float q) { return FAST ? q : fminf(q, 1.0f); }
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
 __device__ __forceinline__ float wendland_eval(const Consts& K, float r) {
     const float q = fminf(K.w_hinv * r, 1.0f);
@@ -118,11 +140,12 @@ __device__ __forceinline__ float wendland_eval(const Consts& K, float r) {
     return K.w_norm * omq_sq * omq_sq * (q + 0.25f);
 }
 // Kernel::gradient_from_positions (kernel.rs:23-28) + WendlandQuinticC2::gradient (wendland_quintic_c2.rs:42-46)
+template <bool FAST>
 __device__ __forceinline__ float2 wendland_grad(const Consts& K, float2 ri, float2 rj) {
     const float dx = rj.x - ri.x, dy = rj.y - ri.y;
     const float r_sq = dx * dx + dy * dy;
-    const float r = sqrt_dist(r_sq);
-    const float q = fminf(r * K.w_hinv, 1.0f);
+    const float r = sqrt_dist<FAST>(r_sq);
+    const float q = clamp_q<FAST>(r * K.w_hinv);
     const float omq = 1.0f - q;
     const float s = K.w_ngrad * omq * omq * omq;
     return make_float2(s * dx, s * dy);
@@ -149,14 +172,13 @@ __device__ __forceinline__ float2 lds_read_f2(const float2* p) {
 __device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p) { return *(lds_cu32*)p; }
 __device__ __forceinline__ float lds_read_f1(const float* p) { return __uint_as_float(*(lds_cu32*)p); }
 
-// three 10-bit list entries in one word
-// (two shifts + two bit-field inserts; whatever c carries above its ten bits lands in bits 30-31, which no reader looks at)
-__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) {
-    constexpr uint32_t M1 = ENTRY_MASK << ENTRY_BITS;
-    uint32_t t = c << (2u * ENTRY_BITS);
-    t = (t & ~M1) | ((b << ENTRY_BITS) & M1);
-    return (t & ~ENTRY_MASK) | (a & ENTRY_MASK);
-}
+// three 10-bit list entries in one word.  Round 5: an entry sits in its field as the BYTE OFFSET of its slot in a
+// 4-byte array — entry u in bits 2 + 10 u .. 11 + 10 u — so that a reader has its LDS address after `and` (entry 0) or `shift right,
+// and` (entries 1, 2): instructions of the part's 2-cycle class (tools/valu_issue_bench.hip), where bit-field extract + shift left
+// (+ a second shift for the second array) were three of the 4-cycle class.  a, b, c: staging slots (< 1024).
+constexpr uint32_t ENTRY_OFF_MASK = ENTRY_MASK << 2;  // 0xffc
+__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return (a << 2) | (b << (ENTRY_BITS + 2u)) | (c << (2u * ENTRY_BITS + 2u)); }
+__device__ __forceinline__ uint32_t entry_off(uint32_t w3, uint32_t u) { return (w3 >> (ENTRY_BITS * u)) & ENTRY_OFF_MASK; }
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
@@ -1132,12 +1154,13 @@ static_assert(WIN_HALO == LIST_HALO && WIN_SLOTS == LIST_WIN && STAGE_ROWS % 4 =
 // ((LIST_WIN + wave * WAVE_REMOTE + line) << 3 | 1: bit 0 marks it — offsets are multiples of eight) once it has given it a line of
 // the out-of-window table.
 __device__ __forceinline__ uint32_t entry_slot(uint32_t E, uint32_t w0) { return w0 + (uint32_t)((int32_t)E >> 3); }
-// three staged entries -> one word of a narrow row (pack3 of their E >> 3; what v2 carries above its ten bits lands in bits 30-31)
+// three staged entries -> one word of a narrow row (pack3 of their E >> 3: slot u lands in bits 2 + 10 u .. 11 + 10 u; the marker bit
+// of a code and whatever a don't-care row carries above its field are masked away)
 __device__ __forceinline__ uint32_t pack3_staged(uint32_t v0, uint32_t v1, uint32_t v2) {
-    constexpr uint32_t M1 = ENTRY_MASK << ENTRY_BITS;
-    uint32_t t = v2 << (2u * ENTRY_BITS - 3u);
-    t = (t & ~M1) | ((v1 << (ENTRY_BITS - 3u)) & M1);
-    return (t & ~ENTRY_MASK) | ((v0 >> 3) & ENTRY_MASK);
+    constexpr uint32_t M0 = ENTRY_OFF_MASK, M1 = ENTRY_OFF_MASK << ENTRY_BITS;
+    uint32_t t = v2 << (2u * ENTRY_BITS - 1u);                  // bits 3..12 of v2 -> 22..31
+    t = (t & ~(M1 | M0)) | ((v1 << (ENTRY_BITS - 1u)) & M1);     // bits 3..12 of v1 -> 12..21
+    return t | ((v0 >> 1) & M0);                                 // bits 3..12 of v0 -> 2..11
 }
 
 template <int MODE>
@@ -1146,7 +1169,11 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                                         float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, bool scan, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
                                         uint32_t (*tile)[STAGE_ROWS][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
-                                        const float* swin, float warm_i) {
+                                        const float* swin, float warm_i
+#ifdef SPHX_STAMPS
+                                        , unsigned long long& stamp_prev_
+#endif
+                                        ) {
     constexpr bool FUSE = MODE >= 1;
     constexpr bool DIV = MODE == 2;
     constexpr bool WARM = MODE == 3;
@@ -1193,6 +1220,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         if (ct == MAX_NEIGHBORS) flags |= DF_NB_CAP;  // "particle has too many neighbors", neighborhood_search.rs:361,376
         if (flags) atomicOr(&scal->flags, flags);
     }
+    SPHX_STAMP(3)
     // ---- wave-uniform facts (scalar registers from here on) -------------------------------------------------------------------
     const uint32_t mct = wave_max_u32(ct);     // the wavefront's longest list
     const uint32_t m = min(mct, STAGE_ROWS);   // ... of it staged in LDS
@@ -1284,45 +1312,49 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             }
         }
         if (FUSE) {
-            auto add = [&](uint32_t u) {
-                const f32x2 d = f32x2{rj[u].x, rj[u].y} - pi2;  // ri_to_rj
-                const f32x2 dd = d * d;
-                const float r = sqrt_dist(dd.x + dd.y);
-                const float q = fminf(r * K.w_hinv, 1.0f);
-                const float omq = 1.0f - q;
-                const float omq_sq = omq * omq;
-                const float t_rho = rho + (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
-                const float sg = K.w_ngrad * omq * omq * omq;
-                const f32x2 sgd = f32x2{sg, sg} * d;  // wendland_grad(ri, rj)
-                const f32x2 g = sgd * mass2;
-                const f32x2 gg = g * g;
-                const f32x2 t_gs = gs2 + g;
-                const float t_gss = gss + (gg.x + gg.y);
-                rho = on[u] ? t_rho : rho;
-                gs2.x = on[u] ? t_gs.x : gs2.x;
-                gs2.y = on[u] ? t_gs.y : gs2.y;
-                gss = on[u] ? t_gss : gss;
-                if (DIV) {  // the operations of k_compute_error<true>
-                    const f32x2 dvg = (vi2 - f32x2{vj[u].x, vj[u].y}) * sgd;
-                    const float t_delta = delta + (dvg.x + dvg.y);
-                    delta = on[u] ? t_delta : delta;
-                }
-                if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
-                    const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
-                    const float sk = k0 + u < cd ? ki + kj : ki;
-                    const f32x2 t_ws = ws + f32x2{sk, sk} * sgd;
-                    ws.x = on[u] ? t_ws.x : ws.x;
-                    ws.y = on[u] ? t_ws.y : ws.y;
+            // (under the exec mask of the lanes that have entry k0 + u — a branch, not selects: the five running sums of MODE 2 were
+            // five v_cndmask_b32 per neighbour, 4 cycles each; round 5)
+            auto add = [&](uint32_t u, auto fast) {
+                if (on[u]) {
+                    const f32x2 d = f32x2{rj[u].x, rj[u].y} - pi2;  // ri_to_rj
+                    const f32x2 dd = d * d;
+                    const float r = sqrt_dist<decltype(fast)::value>(dd.x + dd.y);
+                    const float q = clamp_q<decltype(fast)::value>(r * K.w_hinv);
+                    const float omq = 1.0f - q;
+                    const float omq_sq = omq * omq;
+                    rho = rho + (K.w_norm * omq_sq * omq_sq * (q + 0.25f)) * K.mass;
+                    const float sg = K.w_ngrad * omq * omq * omq;
+                    const f32x2 sgd = f32x2{sg, sg} * d;  // wendland_grad(ri, rj)
+                    const f32x2 g = sgd * mass2;
+                    const f32x2 gg = g * g;
+                    gs2 = gs2 + g;
+                    gss = gss + (gg.x + gg.y);
+                    if (DIV) {  // the operations of k_compute_error<true>
+                        const f32x2 dvg = (vi2 - f32x2{vj[u].x, vj[u].y}) * sgd;
+                        delta = delta + (dvg.x + dvg.y);
+                    }
+                    if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
+                        const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
+                        const float sk = k0 + u < cd ? ki + kj : ki;
+                        ws = ws + f32x2{sk, sk} * sgd;
+                    }
                 }
             };
-            add(0);
-            add(1);
-            if (mct > k0 + 2u) {  // (scalar)
-                add(2);
-                add(3);
-            }
+            auto add4 = [&](auto fast) {
+                add(0, fast);
+                add(1, fast);
+                if (mct > k0 + 2u) {  // (scalar)
+                    add(2, fast);
+                    add(3, fast);
+                }
+            };
+            if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist — the build's own lists are never stale)
+                add4(std::true_type{});
+            else
+                add4(std::false_type{});
         }
     }
+    SPHX_STAMP(4)
     float div_err = 0.0f;
     if (FUSE && live) {
         const float gsx = gs2.x, gsy = gs2.y, wsx = ws.x, wsy = ws.y;
@@ -1395,6 +1427,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             }
         }
     }
+    SPHX_STAMP(5)
     // total number of list entries and of out-of-window entries (stats only): one pair of striped atomics per wavefront
     const uint32_t tot = wave_sum_u32(ct);
     if (lane == 0) {
@@ -1586,7 +1619,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, scan, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i);
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, scan, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i
+#ifdef SPHX_STAMPS
+                  , stamp_prev_
+#endif
+                  );
     SPHX_STAMP(7)
 }
 
@@ -1714,8 +1751,12 @@ __device__ __forceinline__ auto nb_stage_load(const NbHead& h, L&& load) -> NbSt
     // (every table line is fetched, used or not: loading lines 64.. only for the wavefronts with more than 64 out-of-window
     // neighbours saved 4 bytes per particle and walk at 16 M (-0.7 % of the step) and cost 3 % at 1 M — the branch waits for the
     // wavefront's count word; profiles/r03_experiments/predict_fusion.txt section 6)
+#ifdef SPHX_ABL_NOREMOTE  // (traffic / timing experiments: the out-of-window records are NOT fetched — results are wrong)
+    for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(h.lw0);
+#else
 #pragma unroll
     for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
+#endif
     return st;
 }
 template <class R, class S>
@@ -1757,21 +1798,25 @@ __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
     for (uint32_t u = 0; u < NR; ++u)
         if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, rrec[u]);
 }
-// Traversal of entries 0..lim-1 in list order.  gather(x) -> record: x = staging slot (narrow) or global slot (wide);
-// consume(record, k) must ignore k >= lim.
+// Traversal of entries 0..lim-1 in list order.  gather_lds(o) -> record: o = BYTE offset of the entry's staging slot in a 4-byte
+// array (entry_off; the staging areas are structures of 4-byte arrays, SoaStage); gather_global(g) -> record of slot g of the [N|B]
+// arrays (wide wavefronts).  consume(record, k) is only called for k < lim, under the exec mask of the lanes that have entry k: the
+// accumulation needs no select (round 4 computed every slot for every lane and selected; compare + select are 4 cycles each on this
+// part, tools/valu_issue_bench.hip), and a slot no lane of the wavefront has is skipped by the same branch.
 template <class GL, class GG, class C>
 __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& gather_lds, GG&& gather_global, C&& consume) {
+#ifdef SPHX_ABL_NOWALK  // (timing experiments: no walk at all — results are wrong)
+    return;
+#endif
     if (!h.wide) {
-        // entries come six to a word pair; the three of a 32-bit word are read from the staging area together, the third is only
-        // consumed when some lane of the wavefront has it: a wavefront whose longest list has 8 entries does 8 entry slots of
-        // arithmetic, one with 9 does 9 (the kernels are bound by vector instructions as much as by bytes at cache-resident sizes)
+        // the three entries of a 32-bit word are read from the staging area together
         auto triple = [&](uint32_t w3, uint32_t k) {
             decltype(gather_lds(0u)) r[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) r[u] = gather_lds((w3 >> (ENTRY_BITS * u)) & ENTRY_MASK);  // entries >= lim hold don't-care values
-            consume(r[0], k);
-            consume(r[1], k + 1u);
-            if (__any(lim > k + 2u)) consume(r[2], k + 2u);
+            for (uint32_t u = 0; u < 3; ++u) r[u] = gather_lds(entry_off(w3, u));  // entries >= lim hold don't-care values (any slot of the staging area)
+#pragma unroll
+            for (uint32_t u = 0; u < 3; ++u)
+                if (k + u < lim) consume(r[u], k + u);
         };
 #pragma unroll
         for (uint32_t q = 0; q < NB_S1; ++q) {
@@ -1796,24 +1841,45 @@ __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& 
             for (int u = 0; u < NB_BATCH; ++u) r[u] = gather_global(jn[u]);
             fetch(k0 + NB_BATCH, jn);  // clamped to the last entry when the list ends here
 #pragma unroll
-            for (int u = 0; u < NB_BATCH; ++u) consume(r[u], k0 + (uint32_t)u);
+            for (int u = 0; u < NB_BATCH; ++u)
+                if (k0 + (uint32_t)u < lim) consume(r[u], k0 + (uint32_t)u);
         }
     }
 }
+
+// The LDS staging area of a traversal kernel: NF arrays of STAGE_SLOTS floats (structure of arrays).  A list entry is the byte
+// offset of its slot in one of them (entry_off), so ONE address register serves all components of a neighbour's record — each a
+// ds_read_b32 with the array's offset as the instruction's immediate (the compiler pairs two of them into a ds_read2st64_b32).
+// Round 4 kept arrays of records (float2 / float4 + a float array): two address registers per neighbour.
+template <uint32_t NF>
+struct SoaStage {
+    float f[NF][STAGE_SLOTS];
+    __device__ __forceinline__ uint32_t base() const { return lds_addr(&f[0][0]); }
+    // component c of the slot at byte offset o
+    template <uint32_t C>
+    __device__ __forceinline__ float get(uint32_t o) const {
+        static_assert(C < NF, "component");
+        return __uint_as_float(lds_load_u32(base() + C * STAGE_SLOTS * 4u + o));
+    }
+};
 
 // a8 / a9 stand-alone (the pieces benches/ and the warm-up drive): densities and alpha factors from a finished list
 // KIND: 0 Wendland, 1 Poly6, 2 Spiky
 template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
-    __shared__ float2 rec[STAGE_SLOTS];
+    __shared__ SoaStage<2> rec;  // x, y
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
-    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec[slot] = r; });
+    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) {
+        rec.f[0][slot] = r.x;
+        rec.f[1][slot] = r.y;
+    });
     __syncthreads();
     if (i >= n) return;
-    const float2 ri = h.wide ? posA[i] : lds_read_f2(&rec[i - h.lw0]);
+    const uint32_t oi = (i - h.lw0) * 4u;
+    const float2 ri = h.wide ? posA[i] : make_float2(rec.get<0>(oi), rec.get<1>(oi));
     const uint32_t ct = h.ct;
     float rho = 0.0f;
     if (DENSITY) {
@@ -1822,31 +1888,40 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
         if (KIND == 2) rho = spiky_eval(K, 0.0f) * K.mass;
     }
     float gss = 0.0f, gsx = 0.0f, gsy = 0.0f;
-    auto consume = [&](float2 rj, uint32_t k) {
-        const bool live = k < ct;
-        const float dx = rj.x - ri.x, dy = rj.y - ri.y;
-        const float r_sq = dx * dx + dy * dy;
-        const float r = sqrt_dist(r_sq);
-        if (DENSITY) {
-            float wv;
-            if (KIND == 0) wv = wendland_eval(K, r);
-            if (KIND == 1) wv = poly6_eval(K, r_sq);
-            if (KIND == 2) wv = spiky_eval(K, r);
-            const float t = rho + wv * K.mass;
-            rho = live ? t : rho;
-        }
-        if (ALPHA) {
-            const float q = fminf(r * K.w_hinv, 1.0f);
-            const float omq = 1.0f - q;
-            const float sg = K.w_ngrad * omq * omq * omq;
-            const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
-            const float tx = gsx + gx, ty = gsy + gy, ts = gss + (gx * gx + gy * gy);
-            gsx = live ? tx : gsx;
-            gsy = live ? ty : gsy;
-            gss = live ? ts : gss;
-        }
+    auto walk = [&](auto fast) {
+        constexpr bool FAST = decltype(fast)::value;
+        auto consume = [&](float2 rj, uint32_t) {
+            const float dx = rj.x - ri.x, dy = rj.y - ri.y;
+            const float r_sq = dx * dx + dy * dy;
+            const float r = sqrt_dist<FAST>(r_sq);
+            if (DENSITY) {
+                float wv;
+                if (KIND == 0) {  // wendland_eval
+                    const float q = clamp_q<FAST>(K.w_hinv * r);
+                    const float omq = 1.0f - q;
+                    const float omq_sq = omq * omq;
+                    wv = K.w_norm * omq_sq * omq_sq * (q + 0.25f);
+                }
+                if (KIND == 1) wv = poly6_eval(K, r_sq);
+                if (KIND == 2) wv = spiky_eval(K, r);
+                rho = rho + wv * K.mass;
+            }
+            if (ALPHA) {
+                const float q = clamp_q<FAST>(r * K.w_hinv);
+                const float omq = 1.0f - q;
+                const float sg = K.w_ngrad * omq * omq * omq;
+                const float gx = (sg * dx) * K.mass, gy = (sg * dy) * K.mass;
+                gsx = gsx + gx;
+                gsy = gsy + gy;
+                gss = gss + (gx * gx + gy * gy);
+            }
+        };
+        nb_traverse(h, ct, [&](uint32_t o) { return make_float2(rec.get<0>(o), rec.get<1>(o)); }, [&](uint32_t g) { return gat(posA, g); }, consume);
     };
-    nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f2(&rec[slot]); }, [&](uint32_t g) { return gat(posA, g); }, consume);
+    if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
+        walk(std::true_type{});
+    else
+        walk(std::false_type{});
     if (DENSITY) density[i] = fmaxf(rho, K.rho0);                                  // fluidparticleworld.rs:229
     if (ALPHA) alpha[i] = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);     // dfsph.rs:94
 }
@@ -2006,8 +2081,7 @@ __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs 
 #endif
 __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
-    __shared__ float4 rec[STAGE_SLOTS];
-    __shared__ float rho_s[STAGE_SLOTS];
+    __shared__ SoaStage<5> rec;  // x, y, vx, vy, density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2018,13 +2092,17 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
     nb_stage(
         h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
         [&](uint32_t slot, const StageRec& r) {
-            rec[slot] = r.pv;
-            rho_s[slot] = r.rho;
+            rec.f[0][slot] = r.pv.x;
+            rec.f[1][slot] = r.pv.y;
+            rec.f[2][slot] = r.pv.z;
+            rec.f[3][slot] = r.pv.w;
+            rec.f[4][slot] = r.rho;
         });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
+        const uint32_t oi = (i - h.lw0) * 4u;
+        const float4 pvi = h.wide ? ldpv(PV, i) : make_float4(rec.get<0>(oi), rec.get<1>(oi), rec.get<2>(oi), rec.get<3>(oi));
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
@@ -2032,22 +2110,21 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
             float4 pv;
             float rho;
         };
-        auto consume = [&](const Rec& r, uint32_t k) {
+        auto consume = [&](const Rec& r, uint32_t) {
             const float dx = r.pv.x - pvi.x, dy = r.pv.y - pvi.y;
             const float r_sq = dx * dx + dy * dy;
             const float f = em * poly6_eval(K, r_sq) / (r.rho * dt);
-            const float tx = ax + f * (r.pv.z - pvi.z), ty = ay + f * (r.pv.w - pvi.w);
-            ax = k < cd ? tx : ax;
-            ay = k < cd ? ty : ay;
+            ax = ax + f * (r.pv.z - pvi.z);
+            ay = ay + f * (r.pv.w - pvi.w);
         };
         nb_traverse(
-            h, cd, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
+            h, cd, [&](uint32_t o) { return Rec{make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)), rec.get<4>(o)}; },
             [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
-    block_vmax_add(vsq, scal, vslot, (uint32_t*)rho_s);
+    block_vmax_add(vsq, scal, vslot, (uint32_t*)&rec.f[4][0]);
 }
 
 // a12: dfsph.rs:484-492 — vel[] becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
@@ -2118,8 +2195,7 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
 // update_accellerations (wscsph.rs:59-118) + max |v + a*dt|^2 (wscsph.rs:158-161)
 __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                           float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
-    __shared__ float4 rec[STAGE_SLOTS];
-    __shared__ float rho_s[STAGE_SLOTS];
+    __shared__ SoaStage<5> rec;  // x, y, vx, vy, density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2130,13 +2206,17 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
     nb_stage(
         h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
         [&](uint32_t slot, const StageRec& r) {
-            rec[slot] = r.pv;
-            rho_s[slot] = r.rho;
+            rec.f[0][slot] = r.pv.x;
+            rec.f[1][slot] = r.pv.y;
+            rec.f[2][slot] = r.pv.z;
+            rec.f[3][slot] = r.pv.w;
+            rec.f[4][slot] = r.rho;
         });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
-        const float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
+        const uint32_t oi = (i - h.lw0) * 4u;
+        const float4 pvi = h.wide ? ldpv(PV, i) : make_float4(rec.get<0>(oi), rec.get<1>(oi), rec.get<2>(oi), rec.get<3>(oi));
         const float rhoi = density[i];
         const uint32_t cd = h.cd, ct = h.ct;
         float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
@@ -2145,32 +2225,35 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
             float4 pv;
             float rho;
         };
-        auto consume = [&](const Rec& q, uint32_t k) {
-            const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
-            const float r_sq = dx * dx + dy * dy;
-            const float r = sqrt_dist(r_sq);
-            float tx, ty;
-            if (k < cd) {
-                const float pj = wcsph_pressure(K, q.rho);
-                const float pu = -K.mass * (pi + pj) / (2.0f * rhoi * q.rho);                   // wscsph.rs:99
-                const float dd = fmaxf(K.sp_h - r, 0.0f);
-                const float sg = K.sp_ngrad * dd * dd / (r + 1.0e-10f);                          // Spiky::gradient, spiky.rs:34-37
-                tx = ax + pu * (sg * dx);
-                ty = ay + pu * (sg * dy);
-                const float f = K.xsph_eps * K.mass * poly6_eval(K, r_sq) / (q.rho * dt);        // xsph.rs:21-23
-                tx = tx + f * (q.pv.z - pvi.z);
-                ty = ty + f * (q.pv.w - pvi.w);
-            } else {
-                const float s = K.wc_boundary_force * spiky_eval(K, r) / r_sq;                   // wscsph.rs:114
-                tx = ax - s * dx;
-                ty = ay - s * dy;
-            }
-            ax = k < ct ? tx : ax;
-            ay = k < ct ? ty : ay;
+        auto walk = [&](auto fast) {
+            auto consume = [&](const Rec& q, uint32_t k) {
+                const float dx = q.pv.x - pvi.x, dy = q.pv.y - pvi.y;  // ri_to_rj
+                const float r_sq = dx * dx + dy * dy;
+                const float r = sqrt_dist<decltype(fast)::value>(r_sq);
+                if (k < cd) {
+                    const float pj = wcsph_pressure(K, q.rho);
+                    const float pu = -K.mass * (pi + pj) / (2.0f * rhoi * q.rho);                   // wscsph.rs:99
+                    const float dd = fmaxf(K.sp_h - r, 0.0f);
+                    const float sg = K.sp_ngrad * dd * dd / (r + 1.0e-10f);                          // Spiky::gradient, spiky.rs:34-37
+                    float tx = ax + pu * (sg * dx);
+                    float ty = ay + pu * (sg * dy);
+                    const float f = K.xsph_eps * K.mass * poly6_eval(K, r_sq) / (q.rho * dt);        // xsph.rs:21-23
+                    ax = tx + f * (q.pv.z - pvi.z);
+                    ay = ty + f * (q.pv.w - pvi.w);
+                } else {
+                    const float s = K.wc_boundary_force * spiky_eval(K, r) / r_sq;                   // wscsph.rs:114
+                    ax = ax - s * dx;
+                    ay = ay - s * dy;
+                }
+            };
+            nb_traverse(
+                h, ct, [&](uint32_t o) { return Rec{make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)), rec.get<4>(o)}; },
+                [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g < soff ? g : i)}; }, consume);
         };
-        nb_traverse(
-            h, ct, [&](uint32_t slot) { return Rec{lds_read_f4(&rec[slot]), lds_read_f1(&rho_s[slot])}; },
-            [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g < soff ? g : i)}; }, consume);
+        if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
+            walk(std::true_type{});
+        else
+            walk(std::false_type{});
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;
@@ -2211,7 +2294,14 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         const uint32_t c0 = blockIdx.x * per, c1 = min(c0 + per, clear_len);
         for (uint32_t k = c0 + threadIdx.x; k < c1; k += 256u) clear_hist[k] = 0u;
     }
-    __shared__ float4 rec[STAGE_SLOTS];
+    __shared__ SoaStage<4> rec;  // x, y, vx, vy
+    auto put = [&](uint32_t slot, const float4& r) {
+        rec.f[0][slot] = r.x;
+        rec.f[1][slot] = r.y;
+        rec.f[2][slot] = r.z;
+        rec.f[3][slot] = r.w;
+    };
+    auto take = [&](uint32_t o) { return make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)); };
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2245,28 +2335,32 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
             __syncthreads();
             dt = dt_s;
         }
-        nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { rec[slot] = predicted(r, g); });
+        nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { put(slot, predicted(r, g)); });
     } else {
-        nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t slot, const float4& r) { rec[slot] = r; });
+        nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, put);
     }
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
     if (i < n) {
         const uint32_t ct = h.ct;
-        float4 pvi = h.wide ? ldpv(PV, i) : lds_read_f4(&rec[i - h.lw0]);
+        float4 pvi = h.wide ? ldpv(PV, i) : take((i - h.lw0) * 4u);
         if (PREDICT && h.wide) pvi = predicted(load_pred(i), i);
         if (!(DIVERGENCE && ct < 9)) {  // dfsph.rs:261
             const float2 ri = make_float2(pvi.x, pvi.y);
             float delta = 0.0f;
-            auto consume = [&](const float4& r, uint32_t k) {
-                const float2 g = wendland_grad(K, ri, make_float2(r.x, r.y));
-                // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
-                const float dvx = pvi.z - r.z, dvy = pvi.w - r.w;
-                const float t = delta + (dvx * g.x + dvy * g.y);
-                delta = k < ct ? t : delta;
+            auto walk = [&](auto fast) {
+                auto consume = [&](const float4& r, uint32_t) {
+                    const float2 g = wendland_grad<decltype(fast)::value>(K, ri, make_float2(r.x, r.y));
+                    // boundary records carry v = 0, so v_i - 0 = v_i is the static form of dfsph.rs:118 / :274
+                    const float dvx = pvi.z - r.z, dvy = pvi.w - r.w;
+                    delta = delta + (dvx * g.x + dvy * g.y);
+                };
+                nb_traverse(h, ct, take, [&](uint32_t g) { return PREDICT ? predicted(load_pred(g), g) : ldpv(PV, g); }, consume);
             };
-            nb_traverse(h, ct, [&](uint32_t slot) { return lds_read_f4(&rec[slot]); },
-                        [&](uint32_t g) { return PREDICT ? predicted(load_pred(g), g) : ldpv(PV, g); }, consume);
+            if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
+                walk(std::true_type{});
+            else
+                walk(std::false_type{});
             if (DIVERGENCE) {
                 e = fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:277-278
             } else {
@@ -2339,8 +2433,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // staged per neighbour: its position and ONE scalar — WARM: its warm-start value; else k = err * alpha of this iteration
     // (12 bytes a record; round 1 kept a packed {pos, k, err} float4 for one-gather-per-neighbour access, which the LDS staging made
     // pointless: 16 bytes written per particle by compute_error, 16 staged per record here)
-    __shared__ float2 pos_s[STAGE_SLOTS];
-    __shared__ float w_s[STAGE_SLOTS];
+    __shared__ SoaStage<3> rec;  // x, y, the scalar
     const float* const wsrc = WARM ? (const float*)warm : kbuf;
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
@@ -2356,13 +2449,18 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         float2 p;
         float w;
     };
+    // warm[] / kbuf[] have no boundary tail.  A boundary record is staged with the scalar 0: its term is k_i alone (dfsph.rs:156 /
+    // :188 / :309 / :339), and k_i + 0 = k_i to the bit (WARM: 0.5 max(0, lim) = 0, lim < 0) — so the walk adds (k_i + k_j) for every
+    // entry and needs no "dynamic or static?" select per neighbour (round 4: add + compare + select, 10 cycles of ~100).  (k_i = -0
+    // would become +0: the sign of a zero summand never reaches the sum, which starts from +0 and therefore is never -0.)
     auto load_rec = [&](uint32_t g) {
-        // warm[] / kbuf[] have no boundary tail; static entries do not use the scalar
-        return StageRec{gat(posA, g), gat(wsrc, g < soff ? g : 0u)};
+        const float w = gat(wsrc, g < soff ? g : 0u);
+        return StageRec{gat(posA, g), g < soff ? w : 0.0f};
     };
     auto store_rec = [&](uint32_t slot, const StageRec& q) {
-        pos_s[slot] = q.p;
-        w_s[slot] = q.w;
+        rec.f[0][slot] = q.p.x;
+        rec.f[1][slot] = q.p.y;
+        rec.f[2][slot] = q.w;
     };
     DirAhead ahead{0xFFFFFFFFu, EMPTY};
     if (!WARM && INV_DT && ca.hist) {
@@ -2418,33 +2516,40 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     __syncthreads();
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
-        const uint32_t cd = h.cd, ct = h.ct;
+        const uint32_t ct = h.ct;
         float ki;
         float2 ri;
         ri = make_float2(pvi.x, pvi.y);
         if (WARM)
             ki = 0.5f * fmaxf(warm_i, lim);
         else
-            ki = h.wide ? kbuf[i] : lds_read_f1(&w_s[i - h.lw0]);
+            ki = h.wide ? kbuf[i] : rec.get<2>((i - h.lw0) * 4u);
         float dx = 0.0f, dy = 0.0f;
         struct Rec {
             float2 p;
             float w;
         };
-        auto consume = [&](const Rec& q, uint32_t k) {
-            const float2 g = wendland_grad(K, ri, q.p);
-            // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: ki alone, dfsph.rs:156 / :188 / :309 / :339
-            const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.w;
-            const float s = k < cd ? ki + kj : ki;
-            const float tx = dx + s * g.x, ty = dy + s * g.y;
-            dx = k < ct ? tx : dx;
-            dy = k < ct ? ty : dy;
+        auto walk = [&](auto fast) {
+            auto consume = [&](const Rec& q, uint32_t) {
+                const float2 g = wendland_grad<decltype(fast)::value>(K, ri, q.p);
+                // (ki + kj), dfsph.rs:151 / :184 / :305 / :335; static neighbours: kj = 0 (staged so), i.e. ki alone, dfsph.rs:156 / :188 / :309 / :339
+                const float kj = WARM ? 0.5f * fmaxf(q.w, lim) : q.w;
+                const float s = ki + kj;
+                dx = dx + s * g.x;
+                dy = dy + s * g.y;
+            };
+            nb_traverse(
+                h, ct, [&](uint32_t o) { return Rec{make_float2(rec.get<0>(o), rec.get<1>(o)), rec.get<2>(o)}; },
+                [&](uint32_t g) {
+                    const float w = gat(wsrc, g < soff ? g : i);
+                    return Rec{gat(posA, g), g < soff ? w : 0.0f};
+                },
+                consume);
         };
-        nb_traverse(
-            h, ct,
-            [&](uint32_t slot) { return Rec{lds_read_f2(&pos_s[slot]), lds_read_f1(&w_s[slot])}; },
-            [&](uint32_t g) { return Rec{gat(posA, g), gat(wsrc, g < soff ? g : i)}; },
-            consume);
+        if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
+            walk(std::true_type{});
+        else
+            walk(std::false_type{});
         float2 o;
         if (INV_DT) {
             o.x = pvi.z - (inv_dt * dx) * K.mass;  // dfsph.rs:159 / :191
@@ -2516,7 +2621,7 @@ __global__ __launch_bounds__(256) void k_export_lists(NbView nb, uint32_t soff, 
             g = *(const uint32_t*)(h.rows + (uint32_t)((k * 64u + h.lane) * 4u));
         } else {
             const uint32_t word = *(const uint32_t*)(h.rows + (k / 3u) * SUBROW_B + h.lane * 4u);
-            const uint32_t slot = (word >> (ENTRY_BITS * (k % 3u))) & ENTRY_MASK;
+            const uint32_t slot = entry_off(word, k % 3u) >> 2;
             g = slot < LIST_WIN ? h.lw0 + slot : nb.remote[(size_t)(i >> 8) * REMOTE_CAP + (slot - LIST_WIN)];
         }
         out[s + k] = g < soff ? g : g - soff;
