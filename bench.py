@@ -620,6 +620,12 @@ def main():
             # iterations and a warm start)
             also.append(window_summary(single_window(1_000_000, 0, 100, 5), "DFSPH 1 M particles from t=0 (BASELINE configs[1])"))
             also.append(window_summary(single_window(1_000_000, 3750, 100, 5), "DFSPH 1 M particles after 3750 steps (iterating regime: Iv = 2 with warm start)"))
+            # ... and the same regime at the headline's own size ("a second window ... violent phase"): the 16 M scene leaves
+            # Id = Iv = 1 around step 1 900 and runs at Iv = 2 with a divergence warm start in every step from ~2 100 to ~3 300
+            # (tools/iter_trace.py, profiles/r05_iter_trace_16M.txt); 2 500 untimed steps cost ~5 s
+            if abs(head["n"] - 16_000_000) < 300_000:
+                also.append(window_summary(single_window(args.particles, 2500, 20, 2),
+                                           "DFSPH 16 M particles after 2500 steps (iterating regime at the headline's size: Iv = 2 with warm start)"))
         n_global, n, scale = head["n"], head["n"], head["scale"]
         out = {
             "metric": "particle-steps/sec (whole node), 2D DFSPH dam-break" if args.solver == "dfsph" else "particle-steps/sec, 2D WCSPH dam-break",

@@ -378,6 +378,89 @@ def test_sphx_multi_equals_the_single_context_bit_for_bit_in_tiling_invariant_mo
     m.close()
 
 
+def _sphx_multi_vs_single_in_tiling_invariant_mode(target, steps, make_multi):
+    """The loop `bench.py --gpus N` runs (sphx_multi, csrc/sphx_tiles.cpp) at a BASELINE config's full size on ONE device, against the
+    single context, both in tiling-invariant mode with fixed 2 + 2 iterations (both warm starts fire from the second step on):
+    bit-equal positions and velocities by particle id, every particle owned exactly once, the same timer, >= 1 re-partition."""
+    import gc
+
+    pos, boundary = dam_break(float(np.sqrt(target / 4050.0)))
+    n = len(pos)
+    assert 0.97 * target < n < 1.03 * target
+    params = y.default_params(fixed_iterations=(2, 2))
+    ctx = y.SphxContext(params)
+    ctx.set_tiling_invariant(True)
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    timer = y.TimeManager()
+    warm = 0
+    for _ in range(steps):
+        vmax = ctx.step_begin(timer.simulation_step(), timer.law(np.float32(0.01)))
+        st = ctx.step_finish(y.duration_as_secs_f32(timer.update_simulation_step(np.float32(0.01), vmax)))
+        warm += st["warmstart_divergence"] + st["warmstart_density"]
+    assert warm >= 2 * (steps - 1)
+    ref = by_id({kk: vv for kk, vv in ctx.download(density=False).items() if kk in ("ids", "pos", "vel")})
+    ctx.close()
+    del ctx
+    gc.collect()
+    m = make_multi(pos, y.default_params(fixed_iterations=(2, 2)))
+    m.set_tiling_invariant(True)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    t2 = y.TimeManager()
+    m.steps(t2, steps)
+    info = m.info()
+    a = by_id({k: v for k, v in m.download().items() if k in ("ids", "pos", "vel")})
+    m.close()
+    assert len(a["ids"]) == n and (a["ids"] == np.arange(n, dtype=np.uint32)).all()  # every particle owned exactly once
+    assert_bits_equal(a["pos"], ref["pos"], "positions, tiling-invariant mode")
+    assert_bits_equal(a["vel"], ref["vel"], "velocities, tiling-invariant mode")
+    assert t2.simulation_step_ns() == timer.simulation_step_ns()
+    assert info["rebalances"] >= 1, info
+    assert info["exchanges"] >= steps + 1, info
+    assert info["owned_local"] == n
+    return info
+
+
+def test_sphx_multi_2x2_tiles_at_64M_equal_the_single_context_bit_for_bit():
+    """BASELINE configs[3] (DFSPH 64 M particles, 2 x 2 spatial tiles) through the C++ tile loop the bench uses, four tile contexts on
+    one MI355X; skewed cuts (30 % / 70 % columns) so that the first re-partition moves them."""
+
+    def make(pos, params):
+        cx, cy = cell_coord(pos, 0), cell_coord(pos, 1)
+        n = len(pos)
+        xcuts = [0, int(np.partition(cx, int(0.3 * n))[int(0.3 * n)]), 65536]
+        ycuts = []
+        for ix in range(2):
+            col = cy[(cx >= xcuts[ix]) & (cx < xcuts[ix + 1])]
+            ycuts.append([0, int(np.partition(col, len(col) // 2)[len(col) // 2]), 65536])
+        m = MultiSolver(params, devices=[0, 0, 0, 0], rebalance_every=2)
+        m.set_grid(xcuts, np.array(ycuts, np.uint32))
+        return m
+
+    _sphx_multi_vs_single_in_tiling_invariant_mode(64.0e6, 4, make)
+
+
+def test_sphx_multi_8_strips_at_128M_equal_the_single_context_bit_for_bit():
+    """BASELINE configs[4] (DFSPH 128 M particles, 8 strips) through the C++ tile loop the bench uses, eight tile contexts on one
+    MI355X; the first strip starts 40 % too wide so that the first re-partition moves the cuts."""
+
+    def make(pos, params):
+        ext = pos.max(0) - pos.min(0)
+        axis = int(ext[1] > ext[0])
+        c = cell_coord(pos, axis)
+        n = len(pos)
+        fr = [0.175] + [0.175 + (1.0 - 0.175) * k / 7.0 for k in range(1, 7)]
+        inner = [int(np.partition(c, int(f * n))[int(f * n)]) for f in fr]
+        cuts = [0] + inner + [65536]
+        assert all(b > a for a, b in zip(cuts[:-1], cuts[1:]))
+        m = MultiSolver(params, devices=[0] * 8, rebalance_every=2)
+        m.set_strips(axis, cuts)
+        return m
+
+    _sphx_multi_vs_single_in_tiling_invariant_mode(128.0e6, 3, make)
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_tile_classification_by_the_last_density_correction_changes_nothing(monkeypatch, overlap):
     """The density loop's last correction holds the advected positions: in a tile it counts the cells of the particles the tile keeps

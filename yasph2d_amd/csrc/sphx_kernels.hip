@@ -1799,7 +1799,7 @@ __device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
         if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, rrec[u]);
 }
 // Traversal of entries 0..lim-1 in list order.  gather_lds(o) -> record: o = BYTE offset of the entry's staging slot in a 4-byte
-// array (entry_off; the staging areas are structures of 4-byte arrays, SoaStage); gather_global(g) -> record of slot g of the [N|B]
+// array (entry_off; the staging areas are structures of 4-byte arrays, Stage); gather_global(g) -> record of slot g of the [N|B]
 // arrays (wide wavefronts).  consume(record, k) is only called for k < lim, under the exec mask of the lanes that have entry k: the
 // accumulation needs no select (round 4 computed every slot for every lane and selected; compare + select are 4 cycles each on this
 // part, tools/valu_issue_bench.hip), and a slot no lane of the wavefront has is skipped by the same branch.
@@ -1847,19 +1847,75 @@ __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& 
     }
 }
 
-// The LDS staging area of a traversal kernel: NF arrays of STAGE_SLOTS floats (structure of arrays).  A list entry is the byte
-// offset of its slot in one of them (entry_off), so ONE address register serves all components of a neighbour's record — each a
-// ds_read_b32 with the array's offset as the instruction's immediate (the compiler pairs two of them into a ds_read2st64_b32).
-// Round 4 kept arrays of records (float2 / float4 + a float array): two address registers per neighbour.
-template <uint32_t NF>
-struct SoaStage {
-    float f[NF][STAGE_SLOTS];
-    __device__ __forceinline__ uint32_t base() const { return lds_addr(&f[0][0]); }
-    // component c of the slot at byte offset o
+// The LDS staging area of a traversal kernel: NV float2 components (position; velocity) and NS scalars per slot.  A list entry is
+// the byte offset of its slot in a 4-byte array (entry_off), so ONE address register (times 1, 2 or 4) serves all components of a
+// neighbour's record, the component's place being the instruction's immediate offset.
+// SPHX_STAGE_LAYOUT: 0 = every float in an array of its own (x[], y[], ...: ds_read2st64_b32 pairs); 1 = every float2 component in
+// an array of float2 (ds_read_b64 at twice the offset), scalars in float arrays; 2 = the float2 components of a slot together in one
+// record (NV = 2: a float4, ONE ds_read_b128 at four times the offset), scalars in float arrays.
+#ifndef SPHX_STAGE_LAYOUT
+#define SPHX_STAGE_LAYOUT 2
+#endif
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+template <uint32_t NV, uint32_t NS>
+struct Stage {
+    static constexpr uint32_t S = STAGE_SLOTS, VB = NV * S * 8u;  // bytes of the vector part
+    float raw[(NV * 2u + NS) * S] __attribute__((aligned(16)));
+    __device__ __forceinline__ uint32_t base() const { return lds_addr(&raw[0]); }
     template <uint32_t C>
-    __device__ __forceinline__ float get(uint32_t o) const {
-        static_assert(C < NF, "component");
-        return __uint_as_float(lds_load_u32(base() + C * STAGE_SLOTS * 4u + o));
+    __device__ __forceinline__ void put_vec(uint32_t slot, float2 v) {
+        static_assert(C < NV, "component");
+        if (SPHX_STAGE_LAYOUT == 0) {
+            raw[(2u * C) * S + slot] = v.x;
+            raw[(2u * C + 1u) * S + slot] = v.y;
+        } else if (SPHX_STAGE_LAYOUT == 1) {
+            ((float2*)raw)[C * S + slot] = v;
+        } else {
+            ((float2*)raw)[slot * NV + C] = v;
+        }
+    }
+    __device__ __forceinline__ void put_vec01(uint32_t slot, float4 v) {  // both float2 components of a slot (NV = 2)
+        static_assert(NV == 2, "two components");
+        if (SPHX_STAGE_LAYOUT == 2) {
+            ((float4*)raw)[slot] = v;
+        } else {
+            put_vec<0>(slot, make_float2(v.x, v.y));
+            put_vec<1>(slot, make_float2(v.z, v.w));
+        }
+    }
+    template <uint32_t C>
+    __device__ __forceinline__ void put_scal(uint32_t slot, float v) {
+        static_assert(C < NS, "component");
+        raw[NV * 2u * S + C * S + slot] = v;
+    }
+    // o = byte offset of the slot in a 4-byte array (4 * slot)
+    template <uint32_t C>
+    __device__ __forceinline__ float2 vec(uint32_t o) const {
+        static_assert(C < NV, "component");
+        if (SPHX_STAGE_LAYOUT == 0) {
+            return make_float2(__uint_as_float(lds_load_u32(base() + (2u * C) * S * 4u + o)), __uint_as_float(lds_load_u32(base() + (2u * C + 1u) * S * 4u + o)));
+        } else if (SPHX_STAGE_LAYOUT == 1) {
+            const unsigned long long v = *(lds_cu64*)(uintptr_t)(base() + C * S * 8u + (o + o));
+            return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+        } else {
+            const unsigned long long v = *(lds_cu64*)(uintptr_t)(base() + C * 8u + o * NV * 2u);
+            return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+        }
+    }
+    __device__ __forceinline__ float4 vec01(uint32_t o) const {
+        static_assert(NV == 2, "two components");
+        if (SPHX_STAGE_LAYOUT == 2) {
+            const f32x4 v = *(lds_cf4*)(uintptr_t)(base() + o * 4u);
+            return make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            const float2 a = vec<0>(o), b = vec<1>(o);
+            return make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    template <uint32_t C>
+    __device__ __forceinline__ float scal(uint32_t o) const {
+        static_assert(C < NS, "component");
+        return __uint_as_float(lds_load_u32(base() + VB + C * S * 4u + o));
     }
 };
 
@@ -1868,18 +1924,15 @@ struct SoaStage {
 template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
-    __shared__ SoaStage<2> rec;  // x, y
+    __shared__ Stage<1, 0> rec;  // position
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
-    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) {
-        rec.f[0][slot] = r.x;
-        rec.f[1][slot] = r.y;
-    });
+    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
     __syncthreads();
     if (i >= n) return;
     const uint32_t oi = (i - h.lw0) * 4u;
-    const float2 ri = h.wide ? posA[i] : make_float2(rec.get<0>(oi), rec.get<1>(oi));
+    const float2 ri = h.wide ? posA[i] : rec.vec<0>(oi);
     const uint32_t ct = h.ct;
     float rho = 0.0f;
     if (DENSITY) {
@@ -1916,7 +1969,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
                 gss = gss + (gx * gx + gy * gy);
             }
         };
-        nb_traverse(h, ct, [&](uint32_t o) { return make_float2(rec.get<0>(o), rec.get<1>(o)); }, [&](uint32_t g) { return gat(posA, g); }, consume);
+        nb_traverse(h, ct, [&](uint32_t o) { return rec.vec<0>(o); }, [&](uint32_t g) { return gat(posA, g); }, consume);
     };
     if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
         walk(std::true_type{});
@@ -2081,7 +2134,7 @@ __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs 
 #endif
 __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
-    __shared__ SoaStage<5> rec;  // x, y, vx, vy, density
+    __shared__ Stage<2, 1> rec;  // position, velocity; density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2092,17 +2145,14 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
     nb_stage(
         h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
         [&](uint32_t slot, const StageRec& r) {
-            rec.f[0][slot] = r.pv.x;
-            rec.f[1][slot] = r.pv.y;
-            rec.f[2][slot] = r.pv.z;
-            rec.f[3][slot] = r.pv.w;
-            rec.f[4][slot] = r.rho;
+            rec.put_vec01(slot, r.pv);
+            rec.put_scal<0>(slot, r.rho);
         });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
         const uint32_t oi = (i - h.lw0) * 4u;
-        const float4 pvi = h.wide ? ldpv(PV, i) : make_float4(rec.get<0>(oi), rec.get<1>(oi), rec.get<2>(oi), rec.get<3>(oi));
+        const float4 pvi = h.wide ? ldpv(PV, i) : rec.vec01(oi);
         const uint32_t cd = h.cd;
         float ax = K.ax, ay = K.ay;
         const float em = K.xsph_eps * K.mass;
@@ -2118,13 +2168,13 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
             ay = ay + f * (r.pv.w - pvi.w);
         };
         nb_traverse(
-            h, cd, [&](uint32_t o) { return Rec{make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)), rec.get<4>(o)}; },
+            h, cd, [&](uint32_t o) { return Rec{rec.vec01(o), rec.scal<0>(o)}; },
             [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g)}; }, consume);
         accel[i] = make_float2(ax, ay);
         const float px = pvi.z + ax * dt, py = pvi.w + ay * dt;
         vsq = tile_owns(K, pvi.x, pvi.y) ? px * px + py * py : 0.0f;  // ghosts of a tile are somebody else's particles
     }
-    block_vmax_add(vsq, scal, vslot, (uint32_t*)&rec.f[4][0]);
+    block_vmax_add(vsq, scal, vslot, (uint32_t*)&rec.raw[0]);
 }
 
 // a12: dfsph.rs:484-492 — vel[] becomes the predicted velocity (the old velocity is dead from here on, dfsph.rs:524).
@@ -2195,7 +2245,7 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
 // update_accellerations (wscsph.rs:59-118) + max |v + a*dt|^2 (wscsph.rs:158-161)
 __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                           float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
-    __shared__ SoaStage<5> rec;  // x, y, vx, vy, density
+    __shared__ Stage<2, 1> rec;  // position, velocity; density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2206,17 +2256,14 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
     nb_stage(
         h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
         [&](uint32_t slot, const StageRec& r) {
-            rec.f[0][slot] = r.pv.x;
-            rec.f[1][slot] = r.pv.y;
-            rec.f[2][slot] = r.pv.z;
-            rec.f[3][slot] = r.pv.w;
-            rec.f[4][slot] = r.rho;
+            rec.put_vec01(slot, r.pv);
+            rec.put_scal<0>(slot, r.rho);
         });
     __syncthreads();
     float vsq = 0.0f;
     if (i < n) {
         const uint32_t oi = (i - h.lw0) * 4u;
-        const float4 pvi = h.wide ? ldpv(PV, i) : make_float4(rec.get<0>(oi), rec.get<1>(oi), rec.get<2>(oi), rec.get<3>(oi));
+        const float4 pvi = h.wide ? ldpv(PV, i) : rec.vec01(oi);
         const float rhoi = density[i];
         const uint32_t cd = h.cd, ct = h.ct;
         float ax = K.gx, ay = K.gy;  // *accelleration = gravity, wscsph.rs:83
@@ -2247,7 +2294,7 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
                 }
             };
             nb_traverse(
-                h, ct, [&](uint32_t o) { return Rec{make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)), rec.get<4>(o)}; },
+                h, ct, [&](uint32_t o) { return Rec{rec.vec01(o), rec.scal<0>(o)}; },
                 [&](uint32_t g) { return Rec{ldpv(PV, g), gat(density, g < soff ? g : i)}; }, consume);
         };
         if (K.q_noclamp)  // (kernel argument: a scalar branch; sqrt_dist)
@@ -2294,14 +2341,9 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         const uint32_t c0 = blockIdx.x * per, c1 = min(c0 + per, clear_len);
         for (uint32_t k = c0 + threadIdx.x; k < c1; k += 256u) clear_hist[k] = 0u;
     }
-    __shared__ SoaStage<4> rec;  // x, y, vx, vy
-    auto put = [&](uint32_t slot, const float4& r) {
-        rec.f[0][slot] = r.x;
-        rec.f[1][slot] = r.y;
-        rec.f[2][slot] = r.z;
-        rec.f[3][slot] = r.w;
-    };
-    auto take = [&](uint32_t o) { return make_float4(rec.get<0>(o), rec.get<1>(o), rec.get<2>(o), rec.get<3>(o)); };
+    __shared__ Stage<2, 0> rec;  // position, velocity
+    auto put = [&](uint32_t slot, const float4& r) { rec.put_vec01(slot, r); };
+    auto take = [&](uint32_t o) { return rec.vec01(o); };
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     const NbHead h = nb_head(nb, blk, i, n);
@@ -2433,7 +2475,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // staged per neighbour: its position and ONE scalar — WARM: its warm-start value; else k = err * alpha of this iteration
     // (12 bytes a record; round 1 kept a packed {pos, k, err} float4 for one-gather-per-neighbour access, which the LDS staging made
     // pointless: 16 bytes written per particle by compute_error, 16 staged per record here)
-    __shared__ SoaStage<3> rec;  // x, y, the scalar
+    __shared__ Stage<1, 1> rec;  // position; the scalar
     const float* const wsrc = WARM ? (const float*)warm : kbuf;
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
@@ -2458,9 +2500,8 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         return StageRec{gat(posA, g), g < soff ? w : 0.0f};
     };
     auto store_rec = [&](uint32_t slot, const StageRec& q) {
-        rec.f[0][slot] = q.p.x;
-        rec.f[1][slot] = q.p.y;
-        rec.f[2][slot] = q.w;
+        rec.put_vec<0>(slot, q.p);
+        rec.put_scal<0>(slot, q.w);
     };
     DirAhead ahead{0xFFFFFFFFu, EMPTY};
     if (!WARM && INV_DT && ca.hist) {
@@ -2523,7 +2564,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         if (WARM)
             ki = 0.5f * fmaxf(warm_i, lim);
         else
-            ki = h.wide ? kbuf[i] : rec.get<2>((i - h.lw0) * 4u);
+            ki = h.wide ? kbuf[i] : rec.scal<0>((i - h.lw0) * 4u);
         float dx = 0.0f, dy = 0.0f;
         struct Rec {
             float2 p;
@@ -2539,7 +2580,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
                 dy = dy + s * g.y;
             };
             nb_traverse(
-                h, ct, [&](uint32_t o) { return Rec{make_float2(rec.get<0>(o), rec.get<1>(o)), rec.get<2>(o)}; },
+                h, ct, [&](uint32_t o) { return Rec{rec.vec<0>(o), rec.scal<0>(o)}; },
                 [&](uint32_t g) {
                     const float w = gat(wsrc, g < soff ? g : i);
                     return Rec{gat(posA, g), g < soff ? w : 0.0f};
