@@ -1679,20 +1679,39 @@ struct NbHead {
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
     const uint32_t* rtab; // this wavefront's quarter of the workgroup's table
     uint32_t g[WAVE_REMOTE / 64];  // this lane's lines of it: [N|B] slots (lines past R: don't-care)
+    uint32_t c_raw;       // the count word (nb_head_late)
 };
 __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
     NbHead h;
     const uint32_t b0 = blk * 256u;
     const bool active = b0 < n;  // the grid is rounded up: workgroups past the last particle have no lists
+    // Every load of the head has a CLAMPED address and no predicate (lanes and workgroups past the last particle read the last
+    // particle's words and never use them: their counts are zero): a predicated load is a branch, and behind the branches of the
+    // round-4 form the compiler's wait-count pass put `s_waitcnt vmcnt(0)` in front of loads that depend on nothing.
+    const uint32_t last = n ? n - 1u : 0u, ic = min(i, last), blkc = min(blk, last >> 8);
     // The table lines are requested before anything else: the addresses of the out-of-window records come from them (the only
     // two-step chain of the staging), and loads return in order — behind the list words they would arrive with the last of those.
-    h.rtab = nb.remote + (size_t)blk * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
+    h.rtab = nb.remote + (size_t)blkc * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
     static_assert(WAVE_REMOTE == 128, "two halves of 64 lines");
-    h.g[0] = active ? (nb.stream ? __builtin_nontemporal_load(&h.rtab[threadIdx.x & 63u]) : h.rtab[threadIdx.x & 63u]) : 0u;
-    if (!nb.lazy_hi) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
-    // clamped, not predicated: behind a branch the compiler unpacks the word INSIDE it and waits for the load there — a whole
-    // round trip before the first of the other loads was even requested
-    const uint32_t craw = nb.counts[min(i, n ? n - 1u : 0u)];
+    const uint32_t lane = threadIdx.x & 63u;
+    h.lane = lane;
+    h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(ic >> 6) * 4096);
+    const uint32_t* const e0 = (const uint32_t*)(h.rows + lane * 4u);
+    uint32_t craw;
+    // (NbView::stream: a context too large for the caches reads the words a walk uses exactly once with the streaming hint)
+    if (nb.stream) {
+        h.g[0] = __builtin_nontemporal_load(&h.rtab[lane]);
+        h.g[1] = nb.lazy_hi ? 0u : h.rtab[lane + 64u];
+        craw = nb.counts[ic];
+#pragma unroll
+        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = __builtin_nontemporal_load(e0 + q * (SUBROW_B / 4u));
+    } else {
+        h.g[0] = h.rtab[lane];
+        h.g[1] = nb.lazy_hi ? 0u : h.rtab[lane + 64u];
+        craw = nb.counts[ic];
+#pragma unroll
+        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = e0[q * (SUBROW_B / 4u)];
+    }
     const uint32_t c = i < n ? craw : 0u;
     h.cd = c & 0x7fu;
     h.ct = (c >> 7) & 0x7fu;
@@ -1701,30 +1720,26 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     const uint32_t ww = wi * 64u < n ? nb.wave[wi] : 0u;
     h.wide = (ww >> 31) != 0;
     h.R = h.wide ? 0u : min(ww & 0x3ffu, WAVE_REMOTE);
-    h.lane = i & 63u;
-    h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
-    // (NbView::stream: a context too large for the caches reads the words a walk uses exactly once with the streaming hint)
-    if (nb.stream) {
+    h.c_raw = c;
 #pragma unroll
-        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? __builtin_nontemporal_load((const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u)) : 0u;
-    } else {
-#pragma unroll
-        for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
-    }
-    // (a workgroup past the last particle — the grid is rounded up to a multiple of eight — stages slot 0: its clamped loads must
-    // not reach past the [N|B] arrays)
-    if (nb.lazy_hi) {  // (everything else a walk needs has been requested by now: the wait for the count word delays nothing but this)
-        h.g[1] = 0u;
-        if (__any((c & COUNT_MANY_LINES) != 0u)) h.g[1] = active ? h.rtab[(threadIdx.x & 63u) + 64u] : 0u;
-    }
-#pragma unroll
-    for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9..11: only for a wavefront that has them
-        h.e[q] = 0u;
-        if (__any(h.ct > 3u * q)) h.e[q] = i < n ? *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u) : 0u;
-    }
+    for (uint32_t q = NB_S0; q < NB_S1; ++q) h.e[q] = 0u;
     h.lw0 = active && b0 > LIST_HALO ? b0 - LIST_HALO : 0u;
     h.lwlen = active ? min(b0 + 256u + LIST_HALO, n) - h.lw0 : 0u;
     return h;
+}
+// The part of the head that depends on the count word: the upper 64 lines of the wavefront's table and the fourth sub-row are only
+// requested when the wavefront has them.  Round 5: this is a function of its own, called BEHIND the window loads of the staging
+// (nb_stage_load) — until then it sat inside nb_head, i.e. in front of them in program order, and its wait for the count word was a
+// full memory round trip during which the window records, the own particle's words and the table's records had not even been
+// requested (the comment there claimed the opposite; the ISA says `s_waitcnt vmcnt(0)` right behind the head's first six loads).
+__device__ __forceinline__ void nb_head_late(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
+    if (nb.lazy_hi) {
+        if (__any((h.c_raw & COUNT_MANY_LINES) != 0u)) h.g[1] = h.rtab[(threadIdx.x & 63u) + 64u];
+    }
+#pragma unroll
+    for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9..11: only for a wavefront that has them
+        if (__any(h.ct > 3u * q)) h.e[q] = *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u);
+    }
 }
 // Fill the staging area: load(g) -> record of slot g of the [N|B] arrays (any type), store(slot, record) writes it to LDS.  Every
 // load of a thread is issued before the first store (the loads of the out-of-window lines wait for nothing but the table lines
@@ -1737,17 +1752,18 @@ struct NbStaged {  // the records a thread has requested for the staging area: w
     uint32_t g[NB_NR];  // [N|B] slots of the table lines
 };
 template <class L>
-__device__ __forceinline__ auto nb_stage_load(const NbHead& h, L&& load) -> NbStaged<decltype(load(0u))> {
+__device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load) -> NbStaged<decltype(load(0u))> {
     NbStaged<decltype(load(0u))> st;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t (&g)[NB_NR] = st.g;
-#pragma unroll
-    for (uint32_t u = 0; u < NB_NR; ++u) g[u] = h.g[u];
 #pragma unroll
     for (uint32_t u = 0; u < NB_NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;
         st.w[u] = load(h.lw0 + min(t, h.lwlen ? h.lwlen - 1u : 0u));  // clamped, not predicated: no branch between the loads
     }
+    nb_head_late(h, nb, blk, i, n);  // (waits for the count word: everything that does not depend on it is in flight)
+#pragma unroll
+    for (uint32_t u = 0; u < NB_NR; ++u) g[u] = h.g[u];
     // (every table line is fetched, used or not: loading lines 64.. only for the wavefronts with more than 64 out-of-window
     // neighbours saved 4 bytes per particle and walk at 16 M (-0.7 % of the step) and cost 3 % at 1 M — the branch waits for the
     // wavefront's count word; profiles/r03_experiments/predict_fusion.txt section 6)
@@ -1772,31 +1788,9 @@ __device__ __forceinline__ void nb_stage_store(const NbHead& h, const NbStaged<R
         if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, st.r[u], st.g[u]);
 }
 template <class L, class S>
-__device__ __forceinline__ void nb_stage(const NbHead& h, L&& load, S&& store) {
-    if (h.lwlen == 0u) return;  // (workgroups past the last particle stage nothing)
-    constexpr uint32_t NW = (LIST_WIN + 255) / 256, NR = WAVE_REMOTE / 64;
-    const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
-    const uint32_t (&g)[NR] = h.g;
-    decltype(load(0u)) wrec[NW], rrec[NR];
-#pragma unroll
-    for (uint32_t u = 0; u < NW; ++u) {
-        const uint32_t t = threadIdx.x + u * 256u;
-        wrec[u] = load(h.lw0 + min(t, h.lwlen - 1u));  // clamped, not predicated: no branch between the loads
-    }
-#ifdef SPHX_ABL_NOREMOTE  // (traffic experiments: the out-of-window records are NOT fetched — results are wrong)
-    for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(h.lw0);
-#else
-#pragma unroll
-    for (uint32_t u = 0; u < NR; ++u) rrec[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
-#endif
-#pragma unroll
-    for (uint32_t u = 0; u < NW; ++u) {
-        const uint32_t t = threadIdx.x + u * 256u;
-        if (t < h.lwlen) store(t, wrec[u]);
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < NR; ++u)
-        if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, rrec[u]);
+__device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, S&& store) {
+    const auto st = nb_stage_load(h, nb, blk, i, n, load);
+    nb_stage_store(h, st, [&](uint32_t slot, const decltype(load(0u))& r, uint32_t) { store(slot, r); });
 }
 // Traversal of entries 0..lim-1 in list order.  gather_lds(o) -> record: o = BYTE offset of the entry's staging slot in a 4-byte
 // array (entry_off; the staging areas are structures of 4-byte arrays, Stage); gather_global(g) -> record of slot g of the [N|B]
@@ -1927,8 +1921,8 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     __shared__ Stage<1, 0> rec;  // position
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbHead h = nb_head(nb, blk, i, n);
-    nb_stage(h, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
+    NbHead h = nb_head(nb, blk, i, n);
+    nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
     __syncthreads();
     if (i >= n) return;
     const uint32_t oi = (i - h.lw0) * 4u;
@@ -2137,13 +2131,13 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
     __shared__ Stage<2, 1> rec;  // position, velocity; density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbHead h = nb_head(nb, blk, i, n);
+    NbHead h = nb_head(nb, blk, i, n);
     struct StageRec {
         float4 pv;
         float rho;
     };
     nb_stage(
-        h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
+        h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2248,13 +2242,13 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
     __shared__ Stage<2, 1> rec;  // position, velocity; density
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbHead h = nb_head(nb, blk, i, n);
+    NbHead h = nb_head(nb, blk, i, n);
     struct StageRec {
         float4 pv;
         float rho;
     };
     nb_stage(
-        h, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
+        h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2346,7 +2340,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     auto take = [&](uint32_t o) { return rec.vec01(o); };
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
-    const NbHead h = nb_head(nb, blk, i, n);
+    NbHead h = nb_head(nb, blk, i, n);
     // this particle's scalars are requested together with everything else (one round trip, not two)
     const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
     const float alpha_i = i < n ? alpha[i] : 0.0f;
@@ -2364,7 +2358,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         // (pa.va.enabled == 0 — tile path: dt is the host's, all-reduced over the tiles; no law here)
         uint32_t vb = 0;
         if (pa.va.enabled && threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
-        const NbStaged<PredRec> st = nb_stage_load(h, load_pred);
+        const NbStaged<PredRec> st = nb_stage_load(h, nb, blk, i, n, load_pred);
         __shared__ float dt_s;
         if (pa.va.enabled && threadIdx.x < 64) {
             const uint32_t b = wave_max_u32(vb);
@@ -2379,7 +2373,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         }
         nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { put(slot, predicted(r, g)); });
     } else {
-        nb_stage(h, [&](uint32_t g) { return ldpv(PV, g); }, put);
+        nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return ldpv(PV, g); }, put);
     }
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
@@ -2477,16 +2471,6 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // pointless: 16 bytes written per particle by compute_error, 16 staged per record here)
     __shared__ Stage<1, 1> rec;  // position; the scalar
     const float* const wsrc = WARM ? (const float*)warm : kbuf;
-    const uint32_t blk = xcd_bid();
-    const uint32_t i = blk * 256 + threadIdx.x;
-    const NbHead h = nb_head(nb, blk, i, n);
-    // (position and velocity of the own particle: two 8-byte loads; only the velocity is written back)
-    const float4 pvi = i < n ? ldpv(PVr{posA, vel}, i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
-    // nothing is read, and nobody had to write that zero either
-    const float warm_i = (i < n && !first) ? warm[i] : 0.0f;
-    // (TILE — TileClassArgs in use: clamped, not predicated; behind a branch the compiler tests the owner bit inside it and waits there)
-    const uint32_t id_i = TILE ? tc.pid[min(i, n - 1u)] : 0u;
     struct StageRec {
         float2 p;
         float w;
@@ -2503,20 +2487,46 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         rec.put_vec<0>(slot, q.p);
         rec.put_scal<0>(slot, q.w);
     };
-    DirAhead ahead{0xFFFFFFFFu, EMPTY};
-    if (!WARM && INV_DT && ca.hist) {
-        // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, with the
-        // staging loads in flight, for the block the particle is in BEFORE it moves (a particle rarely changes its 64 x 64 block)
-        const NbStaged<StageRec> st = nb_stage_load(h, load_rec);
-        if (i < n) {
-            uint32_t cx0, cy0;
-            cell_of(K, make_float2(pvi.x, pvi.y), cx0, cy0);
-            ahead = dir_ahead(ca.g, cx0, cy0);
+    // Everything the block needs from global memory, requested in one go (Loaded).  (Round 5 tried workgroups that do TWO consecutive
+    // blocks, the second block's requests going out before the first block's walk begins: 64 registers, eight workgroups per CU
+    // kept — and slower at both sizes, 174.7 against 169.6 us at 16 M, 15.6 against 12.7 us at 1 M:
+    // profiles/r05_experiments/two_blocks_per_workgroup.txt.)
+    struct Loaded {
+        uint32_t blk, i;
+        NbHead h;
+        float4 pvi;
+        float warm_i;
+        uint32_t id_i;
+        NbStaged<StageRec> st;
+        DirAhead ahead;
+    };
+    auto load_block = [&](uint32_t blk) {
+        Loaded L;
+        L.blk = blk;
+        L.i = blk * 256 + threadIdx.x;
+        L.h = nb_head(nb, blk, L.i, n);
+        // (position and velocity of the own particle: two 8-byte loads; only the velocity is written back)
+        L.pvi = L.i < n ? ldpv(PVr{posA, vel}, L.i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
+        // nothing is read, and nobody had to write that zero either
+        L.warm_i = (L.i < n && !first) ? warm[L.i] : 0.0f;
+        // (TILE — TileClassArgs in use: clamped, not predicated; behind a branch the compiler tests the owner bit inside it and waits there)
+        L.id_i = TILE ? tc.pid[min(L.i, n - 1u)] : 0u;
+        L.st = nb_stage_load(L.h, nb, blk, L.i, n, load_rec);
+        L.ahead = DirAhead{0xFFFFFFFFu, EMPTY};
+        if (!WARM && INV_DT && ca.hist) {
+            // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, with the
+            // staging loads in flight, for the block the particle is in BEFORE it moves (a particle rarely changes its 64 x 64 block)
+            if (L.i < n) {
+                uint32_t cx0, cy0;
+                cell_of(K, make_float2(L.pvi.x, L.pvi.y), cx0, cy0);
+                L.ahead = dir_ahead(ca.g, cx0, cy0);
+            }
         }
-        nb_stage_store(h, st, [&](uint32_t slot, const StageRec& q, uint32_t) { store_rec(slot, q); });
-    } else {
-        nb_stage(h, load_rec, store_rec);
-    }
+        return L;
+    };
+    const Loaded LA = load_block(xcd_bid());
+    if (LA.h.lwlen) nb_stage_store(LA.h, LA.st, [&](uint32_t slot, const StageRec& q, uint32_t) { store_rec(slot, q); });
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
         residual_wave_reduce(hi, lo);
@@ -2554,6 +2564,16 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
             publish_common(scal, ra.mb, ra.seq);
         }
     }
+    auto process = [&](const Loaded& L) {
+    const uint32_t i = L.i, blk = L.blk;
+    const NbHead& h = L.h;
+    const float4 pvi = L.pvi;
+    const float warm_i = L.warm_i;
+    const uint32_t id_i = L.id_i;
+    const DirAhead ahead = L.ahead;
+    (void)blk;
+    (void)id_i;
+    (void)ahead;
     __syncthreads();
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
@@ -2635,6 +2655,8 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
             }
             count_cell(K, ca.g, i < n, i, pnew, ca.hist, ca.cidx, ca.slot, 1u, scal, ahead);  // every density correction counts
         }
+    };
+    process(LA);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
