@@ -1655,7 +1655,13 @@ static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % 3 == 0 && LIST_WIN + REMOTE_
 // round 3 kept six entries in an 8-byte word per lane, i.e. 1 024 bytes for the same wavefront (lines are fetched whole: the unused
 // upper halves came along).  The first NB_S0 sub-rows are requested up front, the fourth when some lane of the wavefront has more than
 // nine entries (known from the count word, like the upper half of the table), the rest on demand.
-constexpr uint32_t NB_S0 = 3, NB_S1 = STAGE_ROWS / 3;
+// Round 5: the sub-rows a wavefront has beyond the first three are requested together, as soon as the count word is known
+// (nb_head_late), for up to NB_S1 = 6 of them (18 entries): until then only the fourth was, and every further one was a load + wait of
+// its own in the middle of the walk — one more dependent round trip per three entries for the wavefronts of the compressed fluid.
+#ifndef SPHX_NB_S1
+#define SPHX_NB_S1 6
+#endif
+constexpr uint32_t NB_S0 = 3, NB_S1 = SPHX_NB_S1;
 
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1673,7 +1679,7 @@ struct NbHead {
     uint32_t cd, ct;      // NeighborRange: dynamic / total neighbours
     uint32_t R;           // entries of this wavefront's quarter of the out-of-window table (0 when wide)
     bool wide;            // this wavefront's lists hold 32-bit global slots (wave-uniform)
-    uint32_t e[NB_S1];    // entries 0..11, three 10-bit staging slots per word (narrow format)
+    uint32_t e[NB_S1];    // entries 0 .. 3 NB_S1 - 1, three 10-bit staging slots per word (narrow format)
     const char* rows;     // this wave's 16 KiB slice of the list buffer
     uint32_t lane;
     uint32_t lw0, lwlen;  // window = sorted slots [lw0, lw0 + lwlen)
@@ -1737,7 +1743,7 @@ __device__ __forceinline__ void nb_head_late(NbHead& h, const NbView& nb, uint32
         if (__any((h.c_raw & COUNT_MANY_LINES) != 0u)) h.g[1] = h.rtab[(threadIdx.x & 63u) + 64u];
     }
 #pragma unroll
-    for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9..11: only for a wavefront that has them
+    for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9 ..: only for a wavefront that has them
         if (__any(h.ct > 3u * q)) h.e[q] = *(const uint32_t*)(h.rows + q * SUBROW_B + h.lane * 4u);
     }
 }
