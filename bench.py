@@ -69,6 +69,20 @@ def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=Tr
     return b
 
 
+def kernel_source_sha256():
+    """Identity of the device code a counter file was taken from: sha256 over the three sources libsphx's kernels are compiled from.
+    roofline.traffic / roofline.valu only quote a profiles/ record whose kernels are the ones being benchmarked."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp"):
+        try:
+            h.update(open(os.path.join(ROOT, "yasph2d_amd", "csrc", f), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -145,7 +159,7 @@ def cpu_baseline(scale, budget_s=8.0, max_steps=20):
                          "sample": f"{r['all_parallel']['steps']} steps, {r['all_parallel']['seconds']:.1f} s"},
         "threads": f"OpenMP in a fresh child process: omp_get_max_threads() = {r['threads']}, omp_get_proc_bind() = {bind}, "
                    f"omp_get_num_places() = {r['omp_num_places']} (environment of the child: OMP_PROC_BIND=close OMP_PLACES=cores)",
-        "sample": f"{r['port']['steps']} DFSPH steps of the same {r['n']}-particle dam-break after 1 warm-up step, C++/OpenMP restatement of "
+        "sample": f"{r['port']['steps']} DFSPH steps of the {r['n']}-particle dam-break (same scene generator as the GPU run) after 1 warm-up step, C++/OpenMP restatement of "
                   f"yasph2d's Rayon path (not the Rust binary; per-step vectors pooled like scratch_buffer.rs), {r['port']['seconds']:.1f} s",
     }
 
@@ -385,9 +399,12 @@ def main():
         import glob
 
         traffic, src = None, None
+        sha = kernel_source_sha256()
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_traffic_*.json"))):
             try:
                 tj = json.load(open(tf))
+                if sha is None or tj.get("kernel_source_sha256") != sha:
+                    continue  # counters of another build of the kernels: not this run's traffic
                 if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
                     traffic, src = tj["bytes_per_launch"][name]["total"], tj["source"] + f" [file {os.path.basename(tf)}" + (
                         f", taken at git {tj['git_head']}]" if "git_head" in tj else "]")
@@ -401,9 +418,12 @@ def main():
         import glob
 
         rec = None
+        sha = kernel_source_sha256()
         for vf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_valu_*.json"))):
             try:
                 vj = json.load(open(vf))
+                if sha is None or vj.get("kernel_source_sha256") != sha:
+                    continue  # counters of another build of the kernels
                 if abs(vj["workload_particles"] - n) < 0.02 * n and name in vj["per_launch"]:
                     rec = dict(vj["per_launch"][name], source=vj["source"] + f" [file {os.path.basename(vf)}" + (f", taken at git {vj['git_head']}]" if "git_head" in vj else "]"))
             except (OSError, KeyError, ValueError):
@@ -495,20 +515,27 @@ def main():
                 "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (which keeps kernels from overlapping their "
                         "neighbours' tails): its sum exceeds ms_per_step; information only",
             }
-            if dominant.startswith("neighbor_build"):
+            vrec = valu_of(dominant, n) if dominant.startswith("neighbor_build") else None
+            if vrec and vrec.get("active_inst_valu"):
                 # The neighbour build is bound by the vector instructions its wavefronts issue, not by its bytes: the
-                # HBM figures above stay (the contract's roofline), the binding resource is stated beside them.
+                # HBM figures above stay (the contract's roofline), the binding resource is stated beside them — only when the committed SQ
+                # counters were taken from THESE kernels (kernel_source_sha256), otherwise the line says "hbm" and nothing about issue.
                 roof["bound"] = "valu"
-                roof["bound_note"] = ("the dominant kernel is bound by vector-instruction issue (valu_issue_frac of every SIMD's cycles over the launch); "
-                                      "achieved / peak / frac are its algorithmic bytes against the HBM peak, as the bench contract prescribes")
-                vrec = valu_of(dominant, n)
-                if vrec and vrec.get("active_inst_valu"):
-                    roof["valu_issue_frac"] = vrec["active_inst_valu"] * 4.0 / (SIMDS * ENGINE_CLOCK_HZ * avg_ms * 1e-3)
-                    roof["valu"] = {"insts_valu_per_wavefront": vrec["insts_valu_per_wave"], "wavefronts": vrec["waves"],
-                                    "sq_active_inst_valu": vrec["active_inst_valu"], "simds": SIMDS, "engine_clock_hz": ENGINE_CLOCK_HZ,
-                                    "formula": "SQ_ACTIVE_INST_VALU * 4 cycles / (SIMDs * engine clock * avg_launch_ms)", "source": vrec["source"]}
-                else:
-                    roof["valu_issue_frac"] = None
+                roof["bound_note"] = ("the dominant kernel is bound by vector-instruction issue; achieved / peak / frac are its algorithmic bytes "
+                                      "against the HBM peak, as the bench contract prescribes")
+                roof["valu_issue_frac"] = vrec["active_inst_valu"] * 4.0 / (SIMDS * ENGINE_CLOCK_HZ * avg_ms * 1e-3)
+                roof["valu"] = {"insts_valu_per_wavefront": vrec["insts_valu_per_wave"], "wavefronts": vrec["waves"],
+                                "sq_active_inst_valu": vrec["active_inst_valu"], "simds": SIMDS, "engine_clock_hz": ENGINE_CLOCK_HZ,
+                                "formula": "SQ_ACTIVE_INST_VALU * 4 cycles / (SIMDs * engine clock * avg_launch_ms): the fraction of every SIMD's "
+                                           "issue slots the launch fills, at the 2.4 GHz peak clock (the chip runs 2.1-2.3 GHz under this load, so "
+                                           "the real fraction is higher)",
+                                "instruction_costs": "measured on this part (tools/valu_issue_bench.hip, profiles/r05_issue_rate_*.txt): a wave64 "
+                                                     "instruction occupies its SIMD for 4 cycles (fma, min/max, shifts left, bit-field, compares, selects, "
+                                                     "DPP, packed f32), 8 cycles (sqrt/rsq/rcp) or 2 cycles (f32 add/sub/mul, mov, integer add/sub, logic, "
+                                                     "right shifts — when a second wavefront co-issues); SQ_ACTIVE_INST_VALU counts ONE 4-cycle slot per "
+                                                     "instruction of the 2- and 4-cycle classes and two per 8-cycle one, so this figure is the slot "
+                                                     "occupancy, an upper bound of the time the SIMD is busy",
+                                "source": vrec["source"]}
         return elapsed, stats, roof
 
     def iteration_stats(stats):
@@ -669,9 +696,16 @@ def main():
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and args.solver == "dfsph":
-            # a bounded sample of the same workload: the same dam-break at 1 M particles (the restatement's cost per particle-step does not
-            # depend on the size; 16 M would be ~7 s per step on this host)
-            out["cpu_baseline"] = cpu_baseline(min(scale, float(np.sqrt(1_000_000 / 4050.0))))
+            # a bounded sample of the headline's OWN workload: the same scene at the same size, one warm-up step and two
+            # timed ones per variant (~6 s per step of the reference-faithful variant at 16 M on the GPU box's host); beside it the 1 M
+            # sample of rounds 1-4, so that the line shows what the size does to the restatement's cost per particle-step
+            out["cpu_baseline"] = cpu_baseline(scale, budget_s=60.0, max_steps=2 if scale > float(np.sqrt(1_500_000 / 4050.0)) else 10)
+            if scale > float(np.sqrt(1_500_000 / 4050.0)):
+                small = cpu_baseline(float(np.sqrt(1_000_000 / 4050.0)), budget_s=4.0, max_steps=10)
+                out["cpu_baseline"]["at_1M_particles"] = {k: small.get(k) for k in ("value", "unit", "cores", "sample")}
+                out["cpu_baseline"]["at_1M_particles"]["all_parallel"] = (small.get("all_parallel") or {}).get("value")
+                if small.get("value") and out["cpu_baseline"].get("value"):
+                    out["cpu_baseline"]["cost_per_particle_step_vs_1M"] = small["value"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         return

@@ -380,8 +380,10 @@ void sphx_shm_close(sphx_shm* h);
  * warm-start values, which the reference leaves bound to their slot when the particles are re-sorted (dfsph.rs:512) — a slot means
  * nothing across tiles, so tiles let them travel with the particle.  With this switch a context orders the particles of a cell by their
  * persistent id (sphx_download's particle_id) and moves the warm-start values with them: a single context, any sphx_multi tiling and
- * the oracle in the same mode then compute the same run (tests/test_gpu_tiles_full.py).  Off by default; tile contexts take the switch
- * for the cell order (their warm-start values always travel). */
+ * the oracle in the same mode then compute the same run (tests/test_gpu_tiles_full.py, tests/test_gpu_multi.py at 64 M / 128 M).  Off by
+ * default; tile contexts take the switch for the cell order (their warm-start values always travel).  Two exceptions: particles with
+ * EQUAL ids (caller-supplied through sphx_multi_upload) keep their previous order among themselves, and a cell with more than 4 096
+ * particles (a collapse to a point; SPHX_FLAG_DENSE_CELL) keeps arrival order — for those the run may depend on the tiling. */
 int sphx_set_tiling_invariant(sphx_ctx* ctx, int on);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */

@@ -536,7 +536,9 @@ struct NeighborLists {  // :297-450
         ranges.assign(n, NeighborRange{0, 0, 0});
         size_t room = n * MAX_NUM_NEIGHBORS;  // :330
 #ifdef ORC_OMP
-        if (g_all_parallel) room += (size_t)omp_get_max_threads() * 16384;  // (the all_parallel variant's chunk tails)
+        // (the all_parallel variant: every thread's open chunk, and the tail a chunk abandons when the next list does not fit — fewer
+        // than 64 entries per 16 Ki: with every list at the 64 cap that is n * 64 / 256 in total)
+        if (g_all_parallel) room += (size_t)omp_get_max_threads() * 16384 + room / 256 + 16384;
 #endif
         if (lists.size() < room) lists.resize(room);
         size.store(0);

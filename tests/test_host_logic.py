@@ -166,3 +166,44 @@ def test_sort9_network_is_a_sorting_network():
             if a[i] > a[j]:
                 a[i], a[j] = a[j], a[i]
         assert a == sorted(a)
+
+
+def test_sort9_monotone_network_sorts_every_box_with_ascending_rows_and_columns():
+    """The 7-comparator network of csrc/sphx_kernels.hip (sort9_monotone), used for a 3 x 3 cell box inside one 64 x 64 block, whose
+    table slots ascend along dx and along dy: the twenty 0-1 matrices with ascending rows and columns (the restricted 0-1 principle),
+    and random integer matrices of that shape — among them real boxes: slot = y bits | x bits of interleaved coordinates."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(y.__file__), "csrc", "sphx_kernels.hip")).read()
+    body = src[src.index("void sort9_monotone("):]
+    body = body[:body.index("}\n")]
+    net = [(int(a), int(b)) for a, b in re.findall(r"SPHX_CE\(c(\d), c(\d)\)", body)]
+    assert len(net) == 7
+
+    def run(a):
+        a = list(a)
+        for i, j in net:
+            if a[i] > a[j]:
+                a[i], a[j] = a[j], a[i]
+        return a
+
+    count = 0
+    for bits in itertools.product([0, 1], repeat=9):
+        m = np.array(bits).reshape(3, 3)
+        if (np.diff(m, axis=0) >= 0).all() and (np.diff(m, axis=1) >= 0).all():
+            count += 1
+            assert run(bits) == sorted(bits)
+    assert count == 20
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        m = np.sort(np.sort(rng.integers(0, 1000, (3, 3)), axis=0), axis=1)
+        assert run(m.reshape(-1)) == sorted(m.reshape(-1))
+
+    def spread(v):  # bit k of v -> bit 2 k
+        return sum(((v >> k) & 1) << (2 * k) for k in range(6))
+
+    for cx in range(1, 63):
+        for cy in range(1, 63, 7):
+            slots = [(spread(cy + dy) << 1) | spread(cx + dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+            assert run(slots) == sorted(slots)

@@ -22,6 +22,17 @@ NAMES = {  # kernel symbol -> bench.py's launch label
 }
 
 
+def kernel_source_sha256():
+    import hashlib
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp"):
+        h.update(open(os.path.join(root, "yasph2d_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def table(path):
     out = {}
     for line in open(path):
@@ -46,5 +57,6 @@ if __name__ == "__main__":
     doc = {"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}
     if len(sys.argv) > 6 and sys.argv[6]:
         doc["git_head"] = sys.argv[6]  # the build the counters were taken from (bench.py quotes it next to roofline.traffic)
+    doc["kernel_source_sha256"] = kernel_source_sha256()  # bench.py only quotes a record taken from the kernels it runs
     json.dump(doc, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(res, indent=1)[:400])

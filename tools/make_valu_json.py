@@ -9,7 +9,7 @@ import json
 import sys
 
 sys.path.insert(0, __file__.rsplit("/", 1)[0])
-from make_traffic_json import NAMES  # noqa: E402  (kernel symbol -> bench.py's launch label)
+from make_traffic_json import NAMES, kernel_source_sha256  # noqa: E402  (kernel symbol -> bench.py's launch label)
 
 
 def main():
@@ -31,6 +31,7 @@ def main():
     doc = {"workload_particles": int(sys.argv[2]), "source": sys.argv[4], "per_launch": res}
     if len(sys.argv) > 5 and sys.argv[5]:
         doc["git_head"] = sys.argv[5]
+    doc["kernel_source_sha256"] = kernel_source_sha256()
     json.dump(doc, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(res, indent=1)[:600])
 

@@ -540,7 +540,9 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
         __syncthreads();
         publish_common(scal, mb, mb_seq);
     }
-    if (skip_out) return;
+    // (k_block_occupancy decides a block's occupancy from its first and last range: with a skipped tile's ranges left as they were
+    // that is only right while a scan tile covers whole directory blocks)
+    static_assert(SCAN1_TILE % BLOCK_CELLS == 0, "the tile_empty skip needs scan tiles made of whole directory blocks (SPHX_SCAN_ITEMS = 16)");
     if (skip_out) return;
     if (full) {
         uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
@@ -722,7 +724,10 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         uint32_t rank = 0;
         for (uint32_t k = s; k < e; ++k) {
             const uint32_t j = order[k];
-            rank += (j != i && j < n_in && (a.u_in[j] & 0x7FFFFFFFu) < me) ? 1u : 0u;
+            // (caller-supplied ids may repeat, sphx_multi_upload: equal ids keep their previous order, so every record still gets a slot
+            // of its own)
+            const uint32_t idj = j < n_in ? a.u_in[j] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+            rank += (j != i && (idj < me || (idj == me && j < i))) ? 1u : 0u;
         }
         dst = s + rank;
     } else if (e - s <= RANK_LOOP_MAX) {
@@ -1055,6 +1060,17 @@ __device__ __forceinline__ void sort9(uint32_t& c0, uint32_t& c1, uint32_t& c2, 
     SPHX_CE(c2, c3)
 }
 
+// The same for nine values that are ALREADY ascending along the rows and along the columns of the 3 x 3 box they come from (wire
+// 3 dy + dx): seven comparators instead of 25 (found by exhaustive search over comparator sequences; the twenty 0-1 matrices with
+// ascending rows and columns are all a network has to sort — thresholding a matrix with ascending rows and columns gives such a 0-1
+// matrix; tests/test_host_logic.py).  min / max are 4-cycle instructions on this part: 72 of the build's ~1 170 instructions.
+__device__ __forceinline__ void sort9_monotone(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& c4, uint32_t& c5, uint32_t& c6,
+                                               uint32_t& c7, uint32_t& c8) {
+    (void)c0;
+    (void)c8;  // (the box's first and last cell are the smallest and the largest)
+    SPHX_CE(c2, c6) SPHX_CE(c1, c3) SPHX_CE(c5, c7) SPHX_CE(c2, c3) SPHX_CE(c3, c4) SPHX_CE(c4, c6) SPHX_CE(c5, c6)
+}
+
 // Fine-table slots of the 3x3 cell box around (cx, cy), ascending.  The fine table is in global Morton order (blocks ranked in
 // Morton order, cells inside a block by the low 12 bits of their code), so sorting the SLOTS sorts the cells by Morton code —
 // no 32-bit codes, no de-interleaving of block coordinates.  lx/ly: the 6 low bits of x-1..x+1 / y-1..y+1 spread to even / odd bit
@@ -1093,7 +1109,14 @@ __device__ __forceinline__ void slots9n(const NbGrid& g, uint32_t cx, uint32_t c
             if (dx == 1 && dy == 1) centre = off;
             slot[dy * 3 + dx] = (off & ~DIRN_FLAG) | (ly[dy] | lx[dx]);  // offsets are multiples of 4096
         }
-    sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
+    // A box that lies inside ONE 64 x 64 block (no cell of it on a block's rim) has all nine cells in that block's part of the table:
+    // slot = offset | ly[dy] | lx[dx] ascends with dx and with dy, and the seven-comparator network sorts it.  Any lane on a rim
+    // (one wavefront in seven at 3.2 particles per cell): the full network for the wavefront.
+    const bool inside = ((cx & 63u) - 1u) < 62u && ((cy & 63u) - 1u) < 62u;
+    if (!__any(!inside))
+        sort9_monotone(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
+    else
+        sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
 }
 __device__ __forceinline__ void ranges9n(const NbGrid& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
 #pragma unroll
@@ -1585,6 +1608,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     const float d2 = q.x + q.y;
                     // (bitwise, not short-circuit: three compares and two scalar ANDs in a straight line — with && the compiler nests
                     // exec-mask branches around three instructions each)
+                    // (bitwise, not short-circuit: three compares and two scalar ANDs in a straight line — with && the compiler nests
+                    // exec-mask branches around three instructions each.  Round 5 tried the range test as ONE unsigned compare of the bit
+                    // pattern — subtract (2 cycles) + compare (4) for compare + compare (4 + 4): the compiler then packs the sums into
+                    // v_pk_add_f32 with three moves and rebuilds the row addresses with 16-bit adds and shift-adds: 63 instead of 56
+                    // instructions per trip)
                     acc[u] = (bool)((int)(u == 0u || rem > 8u * u) & (int)(d2 <= K.radius_sq) & (int)(d2 > 1.0e-10f));  // (rem >= 8 inside the loop)
                 }
                 // every candidate is WRITTEN to the row the running address points at; a rejected one is overwritten by the next accepted
@@ -1805,8 +1833,15 @@ __device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t b
 // part, tools/valu_issue_bench.hip), and a slot no lane of the wavefront has is skipped by the same branch.
 template <class GL, class GG, class C>
 __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& gather_lds, GG&& gather_global, C&& consume) {
-#ifdef SPHX_ABL_NOWALK  // (timing experiments: no walk at all — results are wrong)
+#ifdef SPHX_ABL_NOWALK  // (timing experiments: no walk at all — results are wrong; the compiler also drops the staging the walk would have read)
     return;
+#endif
+#ifdef SPHX_ABL_ONEENTRY  // (timing experiments: everything is loaded and staged, but only ONE entry is walked — results are wrong)
+    {
+        asm volatile("" ::"v"(h.e[0]), "v"(h.e[1]), "v"(h.e[2]), "v"(h.e[3]));
+        if (lim) consume(gather_lds(entry_off(h.e[0], 0u)), 0u);
+        return;
+    }
 #endif
     if (!h.wide) {
         // the three entries of a 32-bit word are read from the staging area together
