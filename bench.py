@@ -27,18 +27,17 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): the practical ceiling of a streaming kernel
-SIMDS = 256 * 4              # 256 CUs x 4 SIMDs (same guide); a wave64 vector instruction occupies its SIMD for 2, 4 or 8 cycles (tools/valu_issue_bench.hip)
+SIMDS = 256 * 4              # 256 CUs x 4 SIMDs (same guide); a wave64 vector instruction occupies its SIMD for 4 cycles
 ENGINE_CLOCK_HZ = 2.4e9      # peak engine clock
 
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
     """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 10-bit
-    list format of this build — every list-consuming traversal moves the 16-bit count word (+ one format word per wavefront), 4/3*kbar of entries (three to a 32-bit
-    word) and 12*rbar of out-of-window table lines (slot + position, round 5; rbar = such entries per particle, ~0.5) instead of the
-    8 + 4*kbar of the 32-bit lists.
+    list format of this build — every list-consuming traversal moves the 16-bit count word (+ one format word per wavefront), 4/3*kbar of entries (six to an 8-byte word)
+    and 4*rbar of out-of-window table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
     folded: list traversals per step that the neighbour build does while it still holds the list in registers (the divergence loop's
     first compute_density_change, or its warm start: SPHX_FUSE_DIV) — their list read does not happen and is not counted."""
-    lst = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 12 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
+    lst = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     if compressed:
         save = (8 + 4 * kbar) - lst  # per traversal
         return (252 + 16 * kbar - 4 * save + Id * (84 + 8 * kbar - 2 * save) + Iv * (80 + 8 * kbar - 2 * save) + (Wd + Wv) * (44 + 4 * kbar - save)
@@ -52,8 +51,8 @@ def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=Tr
     velocities are separate 8-byte arrays (a velocity-only pass moves 8 bytes, not 16), the first correction of a loop neither reads
     nor zeroes the warm-start value, the divergence loop's first compute_density_change (or its warm start) rides on the neighbour
     build, the velocity prediction on the density loop's first compute_density_error when no warm start precedes it (the acceleration
-    read and the velocity written there: 16 bytes instead of a pass of 24), and a list is 2 + 4/3 k + 12 r bytes (a table line: slot + position)."""
-    L = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 12 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
+    read and the velocity written there: 16 bytes instead of a pass of 24), and a list is 2 + 4/3 k + 4 r bytes."""
+    L = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     nonpressure = 16 + 4 + L + 8
     predict = (24 * min(Wd, 1.0) + 16 * (1.0 - min(Wd, 1.0))) if fuse_predict else 24
     dens_iter_first = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 4 + 8)   # compute_error + correction (+ the re-grid's cell count: 8)
@@ -561,7 +560,7 @@ def main():
                               "sustains over the step is achieved_GBs_this_build_per_gpu",
                 "achieved_GBs_this_build_per_gpu": blay * n * steps / elapsed / 1e9,
                 "frac_of_hbm_peak_this_build": blay * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, three to a 32-bit word, out-of-window table lines of slot + position (32-bit fallback per wavefront)",
+                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, six to an 8-byte word (32-bit fallback per wavefront)",
                 "mean_neighbors": kb, "out_of_window_entries_per_particle": rb,
                 "k_and_r": "measured: list entries of the latest neighbour build / particles it ran over" if measured_k else "not measured",
                 "list_traversals_folded_into_the_neighbour_build_per_step": folded,
