@@ -109,14 +109,6 @@ struct NbView {
     // particles) reads them with the nontemporal hint (-1 % at 16 M; at 1 M, where the lists of one walk are still in the Infinity
     // Cache for the next, the hint costs 1-5 %: profiles/r04_experiments/scan_touched_tiles.txt).  SPHX_STREAM_LISTS=0/1 overrides.
     uint32_t stream;
-    // round 5: every line of the out-of-window table also carries the POSITION of the neighbour it names (rpos, written by the build).
-    // Positions do not change between a build and the next advection, so a walk takes them from the table — a coalesced read that is
-    // in flight with the walk's first loads — and gathers only the fields that change from kernel to kernel (k, velocity, density):
-    // one scattered 8-byte read per line less (each costs a 32-64 byte sector of HBM traffic), and no gather at all for kernels that
-    // only need positions.  use_rpos = 0: positions were replaced behind the lists' back (sphx_upload; like the reference, the walk then
-    // reads the NEW positions through the old lists) or SPHX_TABLE_POS=0: every field is gathered.
-    const float2* rpos;
-    uint32_t use_rpos;
 };
 constexpr uint32_t COUNT_MANY_LINES = 1u << 14;  // count word: the wavefront's table holds more than 64 lines
 // positions + velocities of the [N|B] arrays as one read view (sphx_kernels.hip: ldpv)
@@ -281,7 +273,6 @@ struct sphx_ctx {
     uint32_t B = 0, capB = 0;  // boundary particles
     uint32_t cached_n = 0;     // alpha_values.len() of the reference (dfsph.rs:419)
     bool uploaded = false, boundary_changed = true, tails_dirty = true, in_step = false;
-    bool lists_fresh = false;   // the neighbour lists (and the positions in the out-of-window table) belong to the positions in posA
     uint32_t fast_walk_ok = 0;  // this smoothing length allows the FAST walks (sqrt_dist); K.q_noclamp = fast_walk_ok while the lists are fresh
     uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
     float step_dt_prev = 0, step_vmax = 0;
@@ -319,8 +310,6 @@ struct sphx_ctx {
     uint16_t* nb_counts = nullptr;  // NeighborRange of every particle (count_dynamic | count_total << 7)
     uint32_t* nb_wave = nullptr;    // per wavefront (64 particles): out-of-window table lines in use | wide << 31
     uint32_t* nb_remote = nullptr;  // per 256-particle workgroup REMOTE_CAP global record indices
-    float2* nb_rpos = nullptr;      // ... and the positions of those records at the time of the build (NbView::rpos)
-    int table_pos = 1;              // SPHX_TABLE_POS=0 (A/B runs): walks gather the positions of out-of-window neighbours like rounds 2-4
     // sphx_step_begin_law: first density iteration queued ahead of the host (its mailbox sequence, warm-start flag, the device's dt)
     uint32_t pre_seq = 0, pre_warm = 0, law_dt_bits = 0;
     bool law_active = false;
@@ -382,8 +371,7 @@ struct sphx_ctx {
     int lazy_table = 1;  // SPHX_LAZY_TABLE=0 (A/B runs): every walk fetches all 128 table lines of its wavefront
     int stream_lists = -1;  // SPHX_STREAM_LISTS=0/1 (A/B runs); -1: by size
     sphx::NbView nbv() const {
-        return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table, stream_lists < 0 ? (N >= 4000000u ? 1u : 0u) : (uint32_t)stream_lists,
-                            (const float2*)nb_rpos, (table_pos && lists_fresh) ? 1u : 0u};
+        return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table, stream_lists < 0 ? (N >= 4000000u ? 1u : 0u) : (uint32_t)stream_lists};
     }
     // scan / reduction scratch
     uint32_t* scan_partials = nullptr;

@@ -1189,7 +1189,7 @@ __device__ __forceinline__ uint32_t pack3_staged(uint32_t v0, uint32_t v1, uint3
 template <int MODE>
 __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_t n, uint32_t soff, const Consts& K, const NbGrid& gs,
                                         uint32_t* __restrict__ list, uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote,
-                                        float2* __restrict__ rpos, float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
+                                        float* __restrict__ density, float* __restrict__ alpha, DevScalars* __restrict__ scal, uint32_t i, uint32_t b0,
                                         uint32_t w0, uint32_t wlen, bool live, bool scan, float2 pi, uint32_t cx, uint32_t cy, bool maybe_static, uint32_t ct,
                                         uint32_t (*tile)[STAGE_ROWS][64], const float2* win, const float2* vwin, float2 vi, const DivArgs& dv,
                                         const float* swin, float warm_i
@@ -1260,7 +1260,6 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
     // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
     uint32_t* const rtab = remote + ((size_t)xcd_bid() * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
-    float2* const rptab = rpos + ((size_t)xcd_bid() * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));  // the lines' positions (NbView::rpos)
     char* const slice = (char*)(list + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     const uint32_t t_row0 = lds_addr(mytile);
     uint32_t run = 0;  // out-of-window entries of the staged rows so far (scalar)
@@ -1330,7 +1329,6 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     // (run <= WAVE_REMOTE — a scalar test — says that every line handed out so far exists: no per-lane bound test)
                     if (far[u] && (run <= WAVE_REMOTE || r < WAVE_REMOTE)) {
                         rtab[r] = gb >> 3;
-                        rptab[r] = FUSE ? rj[u] : *(const float2*)((const char*)posA + gb);  // (FUSE: re-read just above)
                         lds_store_u32(ta + u * ROW_B, (r << 3) + ((rbase << 3) | 1u));
                     }
                 }
@@ -1440,10 +1438,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     const bool on = k0 + u < ct;
                     const uint32_t g = on ? list[ell_index(i, k0 + u)] : w0;
                     const bool rem = on && g - w0 >= wlen;
-                    if (rem) {
-                        rtab[r] = g;
-                        rptab[r] = gat(posA, g);
-                    }
+                    if (rem) rtab[r] = g;
                     sl[u] = rem ? rbase + r : g - w0;
                     r += rem ? 1u : 0u;
                 }
@@ -1478,8 +1473,8 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8, MODE == 2 ? SPHX_NB_WAVES_M2 : MODE == 3 ? SPHX_NB_WAVES_M3 : 8))) void k_neighbor_build(
     const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K, NbGrid gd, NbGrid gs, uint32_t* __restrict__ list,
-    uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote, float2* __restrict__ rpos, float* __restrict__ density,
-    float* __restrict__ alpha, DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
+    uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
+    DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
     if (xcd_bid() * 256 >= n) return;
     // (one object, the window first: at LDS offset 0 the four slots of a trip are one clamped base register + immediate offsets)
@@ -1652,7 +1647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #endif
     }
     SPHX_STAMP(2)
-    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, rpos, density, alpha, scal, i, b0, w0, wlen, live, scan, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i
+    nb_tail<MODE>(posA, n, soff, K, gs, list, counts, wave, remote, density, alpha, scal, i, b0, w0, wlen, live, scan, pi, cx, cy, maybe_static, ct, tile, win, vwin, vi, dv, swin, warm_i
 #ifdef SPHX_STAMPS
                   , stamp_prev_
 #endif
@@ -1719,8 +1714,6 @@ struct NbHead {
     const uint32_t* rtab; // this wavefront's quarter of the workgroup's table
     uint32_t g[WAVE_REMOTE / 64];  // this lane's lines of it: [N|B] slots (lines past R: don't-care)
     uint32_t c_raw;       // the count word (nb_head_late)
-    const float2* rptab;  // NbView::rpos: the positions of this wavefront's table lines (nullptr: gather them)
-    float2 gp[WAVE_REMOTE / 64];
 };
 __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
     NbHead h;
@@ -1739,22 +1732,16 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
     h.rows = (const char*)(nb.list + (size_t)__builtin_amdgcn_readfirstlane(ic >> 6) * 4096);
     const uint32_t* const e0 = (const uint32_t*)(h.rows + lane * 4u);
     uint32_t craw;
-    // (the positions of the table lines, NbView::rpos: always loaded — a predicate would be one more branch in front of the loads; whether
-    // they are USED is decided in nb_stage_load)
-    h.rptab = nb.rpos + (size_t)blkc * REMOTE_CAP + (threadIdx.x >> 6) * WAVE_REMOTE;
-    h.g[1] = 0u;
-    h.gp[1] = make_float2(0.0f, 0.0f);
     // (NbView::stream: a context too large for the caches reads the words a walk uses exactly once with the streaming hint)
     if (nb.stream) {
         h.g[0] = __builtin_nontemporal_load(&h.rtab[lane]);
-        const unsigned long long q0 = __builtin_nontemporal_load((const unsigned long long*)&h.rptab[lane]);
-        h.gp[0] = make_float2(__uint_as_float((uint32_t)q0), __uint_as_float((uint32_t)(q0 >> 32)));
+        h.g[1] = nb.lazy_hi ? 0u : h.rtab[lane + 64u];
         craw = nb.counts[ic];
 #pragma unroll
         for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = __builtin_nontemporal_load(e0 + q * (SUBROW_B / 4u));
     } else {
         h.g[0] = h.rtab[lane];
-        h.gp[0] = h.rptab[lane];
+        h.g[1] = nb.lazy_hi ? 0u : h.rtab[lane + 64u];
         craw = nb.counts[ic];
 #pragma unroll
         for (uint32_t q = 0; q < NB_S0; ++q) h.e[q] = e0[q * (SUBROW_B / 4u)];
@@ -1780,10 +1767,8 @@ __device__ __forceinline__ NbHead nb_head(const NbView& nb, uint32_t blk, uint32
 // full memory round trip during which the window records, the own particle's words and the table's records had not even been
 // requested (the comment there claimed the opposite; the ISA says `s_waitcnt vmcnt(0)` right behind the head's first six loads).
 __device__ __forceinline__ void nb_head_late(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n) {
-    // (the upper 64 lines of the wavefront's table: only when it uses them — NbView::lazy_hi = 0 fetches them always, for A/B runs)
-    if (!nb.lazy_hi || __any((h.c_raw & COUNT_MANY_LINES) != 0u)) {
-        h.g[1] = h.rtab[(threadIdx.x & 63u) + 64u];
-        h.gp[1] = h.rptab[(threadIdx.x & 63u) + 64u];
+    if (nb.lazy_hi) {
+        if (__any((h.c_raw & COUNT_MANY_LINES) != 0u)) h.g[1] = h.rtab[(threadIdx.x & 63u) + 64u];
     }
 #pragma unroll
     for (uint32_t q = NB_S0; q < NB_S1; ++q) {  // entries 9 ..: only for a wavefront that has them
@@ -1800,10 +1785,8 @@ struct NbStaged {  // the records a thread has requested for the staging area: w
     R w[NB_NW], r[NB_NR];
     uint32_t g[NB_NR];  // [N|B] slots of the table lines
 };
-// load(g): the whole record of slot g; load_far(g, p): the record of an out-of-window neighbour whose position p came with its table
-// line (NbView::rpos) — only the fields that change between kernels are gathered.
-template <class L, class LF>
-__device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, LF&& load_far) -> NbStaged<decltype(load(0u))> {
+template <class L>
+__device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load) -> NbStaged<decltype(load(0u))> {
     NbStaged<decltype(load(0u))> st;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t (&g)[NB_NR] = st.g;
@@ -1821,13 +1804,8 @@ __device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint3
 #ifdef SPHX_ABL_NOREMOTE  // (traffic / timing experiments: the out-of-window records are NOT fetched — results are wrong)
     for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(h.lw0);
 #else
-    if (nb.use_rpos) {  // (kernel argument: a scalar branch)
 #pragma unroll
-        for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load_far(lane + u * 64u < h.R ? g[u] : h.lw0, h.gp[u]);
-    } else {
-#pragma unroll
-        for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
-    }
+    for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
 #endif
     return st;
 }
@@ -1843,9 +1821,9 @@ __device__ __forceinline__ void nb_stage_store(const NbHead& h, const NbStaged<R
     for (uint32_t u = 0; u < NB_NR; ++u)
         if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, st.r[u], st.g[u]);
 }
-template <class L, class LF, class S>
-__device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, LF&& load_far, S&& store) {
-    const auto st = nb_stage_load(h, nb, blk, i, n, load, load_far);
+template <class L, class S>
+__device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, S&& store) {
+    const auto st = nb_stage_load(h, nb, blk, i, n, load);
     nb_stage_store(h, st, [&](uint32_t slot, const decltype(load(0u))& r, uint32_t) { store(slot, r); });
 }
 // Traversal of entries 0..lim-1 in list order.  gather_lds(o) -> record: o = BYTE offset of the entry's staging slot in a 4-byte
@@ -1985,7 +1963,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     const uint32_t blk = xcd_bid();
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
-    nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t, float2 p) { return p; }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
+    nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
     __syncthreads();
     if (i >= n) return;
     const uint32_t oi = (i - h.lw0) * 4u;
@@ -2201,10 +2179,6 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
     };
     nb_stage(
         h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
-        [&](uint32_t g, float2 p) {
-            const float2 v = gat(PV.vel, g);
-            return StageRec{make_float4(p.x, p.y, v.x, v.y), gat(density, g < soff ? g : 0u)};
-        },
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2316,10 +2290,6 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
     };
     nb_stage(
         h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
-        [&](uint32_t g, float2 p) {
-            const float2 v = gat(PV.vel, g);
-            return StageRec{make_float4(p.x, p.y, v.x, v.y), gat(density, g < soff ? g : 0u)};
-        },
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2429,10 +2399,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         // (pa.va.enabled == 0 — tile path: dt is the host's, all-reduced over the tiles; no law here)
         uint32_t vb = 0;
         if (pa.va.enabled && threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
-        const NbStaged<PredRec> st = nb_stage_load(h, nb, blk, i, n, load_pred, [&](uint32_t g, float2 p) {
-            const float2 v = gat(PV.vel, g);
-            return PredRec{make_float4(p.x, p.y, v.x, v.y), gat(pa.accel, g < soff ? g : 0u)};
-        });
+        const NbStaged<PredRec> st = nb_stage_load(h, nb, blk, i, n, load_pred);
         __shared__ float dt_s;
         if (pa.va.enabled && threadIdx.x < 64) {
             const uint32_t b = wave_max_u32(vb);
@@ -2447,12 +2414,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         }
         nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { put(slot, predicted(r, g)); });
     } else {
-        nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return ldpv(PV, g); },
-                 [&](uint32_t g, float2 p) {
-                     const float2 v = gat(PV.vel, g);
-                     return make_float4(p.x, p.y, v.x, v.y);
-                 },
-                 put);
+        nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return ldpv(PV, g); }, put);
     }
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
@@ -2591,10 +2553,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         L.warm_i = (L.i < n && !first) ? warm[L.i] : 0.0f;
         // (TILE — TileClassArgs in use: clamped, not predicated; behind a branch the compiler tests the owner bit inside it and waits there)
         L.id_i = TILE ? tc.pid[min(L.i, n - 1u)] : 0u;
-        L.st = nb_stage_load(L.h, nb, blk, L.i, n, load_rec, [&](uint32_t g, float2 p) {
-            const float w = gat(wsrc, g < soff ? g : 0u);
-            return StageRec{p, g < soff ? w : 0.0f};
-        });
+        L.st = nb_stage_load(L.h, nb, blk, L.i, n, load_rec);
         L.ahead = DirAhead{0xFFFFFFFFu, EMPTY};
         if (!WARM && INV_DT && ca.hist) {
             // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, with the
