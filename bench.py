@@ -27,13 +27,13 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on it (same guide): the practical ceiling of a streaming kernel
-SIMDS = 256 * 4              # 256 CUs x 4 SIMDs (same guide); a wave64 vector instruction occupies its SIMD for 4 cycles
+SIMDS = 256 * 4              # 256 CUs x 4 SIMDs (same guide); a wave64 vector instruction occupies its SIMD for 2, 4 or 8 cycles (tools/valu_issue_bench.hip)
 ENGINE_CLOCK_HZ = 2.4e9      # peak engine clock
 
 
 def bytes_per_particle_step(kbar, Id, Iv, Wd, Wv, compressed=False, rbar=0.5, folded=0.0):
     """SURVEY.md §8(d) / BASELINE.md §4 list-based algorithmic bytes per particle-step.  compressed: the workgroup-local 10-bit
-    list format of this build — every list-consuming traversal moves the 16-bit count word (+ one format word per wavefront), 4/3*kbar of entries (six to an 8-byte word)
+    list format of this build — every list-consuming traversal moves the 16-bit count word (+ one format word per wavefront), 4/3*kbar of entries (three to a 32-bit word)
     and 4*rbar of out-of-window table lines (rbar = such entries per particle, ~0.5) instead of the 8 + 4*kbar of the 32-bit lists.
     folded: list traversals per step that the neighbour build does while it still holds the list in registers (the divergence loop's
     first compute_density_change, or its warm start: SPHX_FUSE_DIV) — their list read does not happen and is not counted."""
@@ -560,7 +560,7 @@ def main():
                               "sustains over the step is achieved_GBs_this_build_per_gpu",
                 "achieved_GBs_this_build_per_gpu": blay * n * steps / elapsed / 1e9,
                 "frac_of_hbm_peak_this_build": blay * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, six to an 8-byte word (32-bit fallback per wavefront)",
+                "list_format": "32-bit" if args.lists_32bit else "workgroup-local 10-bit slots, three to a 32-bit word (32-bit fallback per wavefront)",
                 "mean_neighbors": kb, "out_of_window_entries_per_particle": rb,
                 "k_and_r": "measured: list entries of the latest neighbour build / particles it ran over" if measured_k else "not measured",
                 "list_traversals_folded_into_the_neighbour_build_per_step": folded,

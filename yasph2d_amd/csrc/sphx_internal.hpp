@@ -46,8 +46,8 @@ constexpr uint32_t WIN_HALO = SPHX_WIN_HALO;      // neighbour build: positions 
 constexpr uint32_t LIST_HALO = SPHX_LIST_HALO;
 constexpr uint32_t LIST_WIN = 256 + 2 * LIST_HALO;
 constexpr uint32_t REMOTE_CAP = 512;
-// a narrow list entry = a slot of the staging area (window + out-of-window table = 1024 slots): ten bits, three to a 32-bit word,
-// six to the 8-byte word a lane owns in one row of its wavefront's slice
+// a narrow list entry = a slot of the staging area (window + out-of-window table = 1024 slots): ten bits, three to the 32-bit word
+// a lane owns in one sub-row of its wavefront's slice, each stored as the slot's byte offset in a 4-byte array (pack3, sphx_kernels.hip)
 constexpr uint32_t ENTRY_BITS = 10, ENTRY_MASK = (1u << ENTRY_BITS) - 1u;
 constexpr uint32_t WAVE_REMOTE = REMOTE_CAP / 4;  // every wavefront of a workgroup owns a quarter of the table (its format is decided per wavefront)
 constexpr uint32_t STRIPES = 32;        // same-address atomics serialise in L2: counters are striped over 32 cache lines

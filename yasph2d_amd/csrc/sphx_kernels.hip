@@ -1254,8 +1254,12 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     // wavefront's quarter of the workgroup's out-of-window table and is stored as LIST_WIN + w * WAVE_REMOTE + r.  Lines are handed
     // out in a fixed order (row, lane).  A wavefront with more than remote_cap / 4 such entries keeps 32-bit global slots (wide; its
     // traversals gather from global memory).
-    // Narrow layout of a wave's slice: entries 6q .. 6q+5 of a lane are one 8-byte word at q * 512 + lane * 8, so a traversal
-    // fetches the first twelve entries of its particle with two coalesced loads that depend on nothing.
+    // Narrow layout of a wave's slice: entries 3q .. 3q+2 of a lane are one 32-bit word at q * 256 + lane * 4 (pack3), so a traversal
+    // fetches the first nine entries of its particle with three coalesced loads that depend on nothing.
+    // (Round 5 tried table lines that also carry the neighbour's POSITION, so that a walk gathers only the fields that change between
+    // kernels: with the switch on, prediction + error and nonpressure gained 6-7 % at 16 M against the same library with it off — and
+    // the library as a whole LOST against the commit before: build +9 %, divergence correction +16 %, 10.1 against 10.75 G particle-
+    // steps/s (profiles/r05_experiments/table_positions.txt).  Reverted.)
     const uint32_t cap = K.remote_cap / 4u;
     const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
     // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
@@ -1416,8 +1420,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             list[(row0 + k) * 64 + lane] = g;
         }
     } else {
-        // three rows = one 32-bit word per lane, half of the 8-byte word the lane owns in a row group (rows >= m of the last word hold
-        // don't-care values: traversals stop at the count)
+        // three rows = one 32-bit word per lane (rows >= m of the last word hold don't-care values: traversals stop at the count)
         const uint32_t lane4 = lane * 4u;
 #pragma unroll
         for (uint32_t k0 = 0; k0 < STAGE_ROWS; k0 += 3u) {
@@ -1659,7 +1662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 // neighbour traversal.  Lists are WORKGROUP-LOCAL (neighborhood_search.rs:262-273 only sketches a compressed layout; README.md:12
 // calls it WIP): the 256 particles of a workgroup look at neighbours that sit, in Morton order, almost always within a few hundred
 // sorted slots of them.  A traversal kernel stages the records of the window [lw0, lw0 + lwlen) and the (few) records named by the
-// workgroup's out-of-window table in LDS with COALESCED loads, and the 16-bit list entries are slots of that staging area: every
+// workgroup's out-of-window table in LDS with COALESCED loads, and the 10-bit list entries are slots of that staging area: every
 // neighbour record is an LDS read.  (Gathering 16-byte records straight from global memory costs one L1 tag lookup per lane and
 // neighbour; the kernels were bound by exactly that.)  A workgroup whose out-of-window table would overflow keeps 32-bit global
 // slots and gathers from global memory (RC_WIDE, bit 31 of its count words) — results never depend on the format.
@@ -1674,8 +1677,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 constexpr uint32_t next_pow2(uint32_t v) { return v <= 1u ? 1u : 2u * next_pow2((v + 1u) / 2u); }
 constexpr uint32_t STAGE_SLOTS = next_pow2(LIST_WIN + REMOTE_CAP);  // LDS staging area (power of two: don't-care list entries are masked into it)
 // A narrow list entry is a slot of that staging area: TEN bits (the window and the out-of-window table together have 1024 slots).
-// Three entries to a 32-bit word, six to the 8-byte word a lane owns in a row of its wavefront's slice: 1.33 bytes per entry
-// (round 2: 16-bit entries, four to the word).
+// Three entries to the 32-bit word a lane owns in a sub-row of its wavefront's slice: 1.33 bytes per entry (round 2: 16-bit entries,
+// four to an 8-byte word).
 static_assert(REMOTE_CAP % 256 == 0 && STAGE_ROWS % 3 == 0 && LIST_WIN + REMOTE_CAP <= (1u << ENTRY_BITS) && STAGE_SLOTS == (1u << ENTRY_BITS),
               "staging loops / packed groups / 10-bit slots");
 // Narrow layout of a wave's slice (round 4): SUB-ROWS of three entries — one 32-bit word per lane, 256 bytes per wavefront; entries
