@@ -86,10 +86,10 @@ def test_update_densities_bench_world(kind):
     assert_bits_equal(ctx.download_solver_state()["alpha"], o.alpha(), "alpha")
 
 
-def run_steps(ctx, o, steps, check_every=1, use_law=True):
+def run_steps(ctx, o, steps, check_every=1, use_law=True, timer=None):
     """use_law: sphx_step_begin_law — the device derives dt from its own vmax and runs ahead of the host; step_finish fails
     unless the host timer arrives at the same bits, so every step also checks the device restatement of the timer law."""
-    timer = y.TimeManager()
+    timer = timer if timer is not None else y.TimeManager()
     diam = np.float32(2.0) * np.float32(0.005)
     all_stats = []
     for s in range(steps):
@@ -242,6 +242,37 @@ def test_fused_count_switch(monkeypatch):
         a, b = ctx.download(), ctx2.download()
         for k in ("pos", "vel", "density"):
             assert_bits_equal(a[k], b[k], k)
+
+
+def test_the_walks_forms_for_stale_lists_follow_the_oracle_too(monkeypatch):
+    """The walks have two arms: FAST — exact rsq-based square root, no min(q, 1) — while the lists belong to the
+    positions, and plain sqrtf + clamp after positions were replaced behind the lists' back (or SPHX_QCLAMP=1).  Both must follow
+    the oracle bit for bit: the switch through the impact with warm starts, and the stale case itself — an upload of DIFFERENT
+    positions with an unchanged particle count, after which the reference (and the oracle) walk the old lists over the new positions,
+    coincident pairs and pairs beyond h included."""
+    pos, boundary = dam_break(1.0)
+    monkeypatch.setenv("SPHX_QCLAMP", "1")
+    ctx, o = make_pair(pos, boundary)
+    run_steps(ctx, o, 200, check_every=40)
+    monkeypatch.delenv("SPHX_QCLAMP")
+    ctx2, o2 = make_pair(pos, boundary)
+    timer2 = y.TimeManager()
+    run_steps(ctx2, o2, 200, check_every=40, timer=timer2)
+    a, b = ctx.download(), ctx2.download()
+    for k in ("pos", "vel", "density"):
+        assert_bits_equal(a[k], b[k], k)
+    # stale lists: shuffle the positions (every list now points at particles somewhere else), put two particles on one spot
+    rng = np.random.default_rng(3)
+    p2 = np.ascontiguousarray(b["pos"][rng.permutation(len(pos))])
+    p2[1] = p2[0]
+    ctx2.upload(p2, b["vel"])
+    o2.set_particles(p2, b["vel"])
+    # (densities are outputs — the oracle's set_particles zeroes them, the device keeps the old ones: recompute them on both sides,
+    # through the stale lists, before the step reads them in the XSPH term)
+    ctx2.update_densities(KERNEL_WENDLAND)
+    o2.update_densities(KERNEL_WENDLAND)
+    assert_bits_equal(ctx2.download()["density"], o2.densities(), "densities through stale lists")
+    run_steps(ctx2, o2, 3, check_every=1, timer=timer2)
 
 
 def test_dfsph_scale_40k():

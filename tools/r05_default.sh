@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the default bench line end to end (what the driver runs), with its wall time.  tools/r05_default.sh OUTNAME
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out; cd $GRAFT_REPO_ROOT
-t0=$(date +%s.%N)
-python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "rc=$? wall=$(echo "$(date +%s.%N) - $t0" | bc) s"
+t0=$(date +%s)
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "rc=$? wall=$(( $(date +%s) - t0 )) s"
 python3 - $out/bench_default.json <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
