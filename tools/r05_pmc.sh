@@ -8,6 +8,5 @@ pass() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --outpu
   f=$(find $out/$name -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 $GRAFT_REPO_ROOT/tools/pmc_table.py $f > $out/$name.txt; find $out/$name -name "*.csv" -delete; find $out -type d -empty -delete; }
 pass lds SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS
 pass vmem SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU
-pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum
-pass ta TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE
-head -12 $out/lds.txt $out/vmem.txt $out/tcc.txt $out/ta.txt
+# (the derived TCC_*_sum / TA_*_sum counters did not finish within 400 s per pass on this pool: not collected)
+head -12 $out/lds.txt $out/vmem.txt
