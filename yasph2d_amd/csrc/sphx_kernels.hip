@@ -1854,7 +1854,17 @@ __device__ __forceinline__ void nb_traverse(const NbHead& h, uint32_t lim, GL&& 
             for (uint32_t u = 0; u < 3; ++u) r[u] = gather_lds(entry_off(w3, u));  // entries >= lim hold don't-care values (any slot of the staging area)
 #pragma unroll
             for (uint32_t u = 0; u < 3; ++u)
-                if (k + u < lim) consume(r[u], k + u);
+                if (k + u < lim) {
+                    consume(r[u], k + u);
+#ifdef SPHX_ABL_HEAVYWALK  // (timing experiments: N more 4-cycle instructions per entry on a register nothing reads — results unchanged)
+                    {
+                        float dummy_ = 1.0f;
+#pragma unroll
+                        for (int z = 0; z < SPHX_ABL_HEAVYWALK; ++z) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy_));
+                        asm volatile("" ::"v"(dummy_));
+                    }
+#endif
+                }
         };
 #pragma unroll
         for (uint32_t q = 0; q < NB_S1; ++q) {
