@@ -275,6 +275,17 @@ def test_the_walks_forms_for_stale_lists_follow_the_oracle_too(monkeypatch):
     run_steps(ctx2, o2, 3, check_every=1, timer=timer2)
 
 
+def test_arrival_slots_that_do_not_fit_the_cell_word_go_through_the_side_array(monkeypatch):
+    """The re-grid keeps a particle's cell index and its arrival slot inside the cell in one 32-bit word (count_cell, GridView::cbits);
+    a slot that does not fit the bits the table size leaves goes to a side array.  With SPHX_CBITS_MIN=30 the word has room for the
+    slots 0..2: every cell with four particles (most cells of the scene) takes the side path — same run as the oracle, bit for bit."""
+    pos, boundary = dam_break(1.0)
+    monkeypatch.setenv("SPHX_CBITS_MIN", "30")
+    ctx, o = make_pair(pos, boundary)
+    run_steps(ctx, o, 120, check_every=40)
+    monkeypatch.delenv("SPHX_CBITS_MIN")
+
+
 def test_dfsph_scale_40k():
     s = float(np.sqrt(40000 / 4050))
     pos, boundary = dam_break(s)

@@ -126,6 +126,9 @@ struct GridView {
     const uint32_t* dir;
     const uint2* fine;  // {first sorted particle of the cell, one past its last}
     uint32_t bx0, by0, nbx, nby;
+    // the re-grid's per-particle word (count_cell): cell index in the low `cbits` bits (the table has fewer than 2^cbits - 1 entries),
+    // the particle's arrival slot inside its cell above them (saturating at cell_slot_max(): then the slot is in the side array)
+    uint32_t cbits;
 };
 // The same grid as the neighbour build reads it (round 4): a second directory `dirn` in which NO entry is special —
 //   * a block the directory does not cover points at the NULL BLOCK, 4096 all-zero entries behind the cell table ({0, 0}: an empty
@@ -246,7 +249,15 @@ struct Grid {
     std::vector<uint32_t> h_dir;  // host copy of dir
     bool fine_valid = false;      // `fine` holds the cell ranges of a build made with THIS directory
     uint32_t len() const { return nblk * BLOCK_CELLS; }
-    GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby}; }
+    uint32_t cbits() const {  // bits of a cell index: len() <= 2^cbits - 1, so that no packed word of count_cell equals EMPTY
+        // (SPHX_CBITS_MIN: a test knob — with 29 a word has room for arrival slots 0..6 only, and ordinary scenes exercise the side array)
+        const char* const knob = getenv("SPHX_CBITS_MIN");
+        const uint32_t floor_bits = knob ? (uint32_t)atoi(knob) : 1u;
+        uint32_t b = floor_bits < 1u ? 1u : floor_bits > 31u ? 31u : floor_bits;
+        while (b < 31u && ((1u << b) - 1u) < len()) ++b;
+        return b;
+    }
+    GridView view() const { return GridView{dir, fine, bx0, by0, nbx, nby, cbits()}; }
     NbGrid nview() const { return nbx && nby ? NbGrid{dirn, fine, bx0, by0, nbx, nbx - 1u, nby - 1u} : NbGrid{dirn, fine, 0u, 0u, 1u, 0u, 0u}; }
 };
 

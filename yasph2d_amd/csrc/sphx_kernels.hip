@@ -567,6 +567,8 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
 }
 
 // what a kernel that ends with the re-grid's cell count (count_cell) is handed
+// the largest arrival slot count_cell's packed word can hold is one less: this value says "look in slot[]"
+__device__ __forceinline__ uint32_t cell_slot_max(uint32_t cbits) { return 0xFFFFFFFFu >> cbits; }
 struct CountArgs {
     GridView g;
     uint32_t *hist, *cidx, *slot;
@@ -580,7 +582,9 @@ struct CountArgs {
 // position update x += v* dt (dfsph.rs:499-510) in front.  Particles arrive almost sorted (they were in cell order one step
 // ago), so equal cells sit in adjacent lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.
 // The value returned by the atomic is an arbitrary arrival slot inside the cell; k_rank_gather restores the stable order.
-// cidx[i] = the particle's index into the fine table (kept for scatter/gather).
+// cidx[i] = the particle's index into the fine table and that arrival slot in ONE word (GridView::cbits; round 5: a second array of
+// slots was 4 bytes per particle written here and 4 read by the scatter) — the slot[] array only receives the slots that do not fit
+// the word's upper bits (a cell with hundreds of particles: a collapse, or strays parked in the table's first cell).
 // Called by ALL lanes of a wavefront (live = this lane holds particle i at position p).
 __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, bool live, uint32_t i, float2 p, uint32_t* __restrict__ hist,
                                            uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring, DevScalars* __restrict__ scal,
@@ -611,7 +615,6 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
             }
         }
         if (f && (__hip_atomic_load(&scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&scal->flags, f);
-        cidx[i] = idx;
     }
     const uint32_t prev = dpp_mov<0x138>(idx, idx);  // wave_shr:1 — the cell of the lane below (lane 0: its own; unused)
     const bool head = (lane == 0) || (idx != prev);
@@ -622,7 +625,11 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
     uint32_t base = 0;
     if (head && idx != EMPTY) base = atomicAdd(&hist[idx], end - lane);
     base = __shfl(base, start, 64);
-    if (live) slot[i] = (idx != EMPTY) ? base + (lane - start) : EMPTY;
+    if (live) {
+        const uint32_t sl = base + (lane - start), sl_max = cell_slot_max(g.cbits);
+        cidx[i] = (idx != EMPTY) ? idx | (min(sl, sl_max) << g.cbits) : EMPTY;
+        if (idx != EMPTY && sl >= sl_max) slot[i] = sl;
+    }
 }
 // first: the pass covers particles [first, n) (the tile path counts the particles it kept while the halo exchange is in flight and
 // the received ones afterwards)
@@ -646,16 +653,35 @@ __global__ __launch_bounds__(256) void k_key_count(PVr PV, const float2* __restr
     count_cell(K, g, i < n, i, p, hist, cidx, slot, ring, scal);
 }
 
-// order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order)
+// order[cell_start + slot] = i  (unstable within a cell; k_rank_gather restores the stable order).  Bit 31 marks the FIRST slot of a
+// cell (arrival slot 0): the gather finds the ends of its cell in the words of order[] it reads anyway (ORDER_HEAD).
+constexpr uint32_t ORDER_HEAD = 0x80000000u, ORDER_INDEX = 0x7FFFFFFFu;  // (contexts hold < 2^28 slots)
+// (Round 5: FOUR particles per lane.  With one, the kernel was two dependent loads and a store per lane — a chip full of such
+// wavefronts keeps ~2 MB in flight and ran at 3.3 TB/s whatever it read; profiles/r05_experiments/regrid.txt.)
+constexpr uint32_t SCATTER_PER_LANE = 4;
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
-                                                  const uint2* __restrict__ fine, uint32_t* __restrict__ order) {
-    const uint32_t i = xcd_bid() * 256 + threadIdx.x;
-    if (i >= n) return;
-    // both words requested together (behind the early return the cell index was a second round trip)
-    const uint32_t sl = slot[i], ci = cidx[i];
-    if (sl == EMPTY || ci == EMPTY) return;
-    const uint32_t p = fine[ci].x + sl;
-    if (p < n) order[p] = i;
+                                                  const uint2* __restrict__ fine, uint32_t* __restrict__ order, uint32_t cbits) {
+    const uint32_t i0 = (xcd_bid() * 256 + threadIdx.x) * SCATTER_PER_LANE;
+    if (i0 >= n) return;
+    uint32_t w[SCATTER_PER_LANE];
+    if (i0 + SCATTER_PER_LANE <= n) {
+        const uint4 v = *(const uint4*)(cidx + i0);  // (hipMalloc'ed array, i0 a multiple of four)
+        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+#pragma unroll
+        for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = i0 + u < n ? cidx[i0 + u] : EMPTY;
+    }
+    uint32_t first[SCATTER_PER_LANE];
+#pragma unroll
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) first[u] = fine[w[u] == EMPTY ? 0u : w[u] & ((1u << cbits) - 1u)].x;  // four gathers in flight
+#pragma unroll
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) {
+        if (w[u] == EMPTY) continue;
+        uint32_t sl = w[u] >> cbits;
+        if (sl == cell_slot_max(cbits)) sl = slot[i0 + u];
+        const uint32_t p = first[u] + sl;
+        if (p < n) order[p] = (i0 + u) | (sl == 0u ? ORDER_HEAD : 0u);
+    }
 }
 
 struct GatherArgs {
@@ -692,60 +718,95 @@ struct GatherArgs {
 // the upper bound n.
 __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cidx, uint32_t n,
                                                       uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a,
-                                                      const uint32_t* __restrict__ n_dev) {
+                                                      const uint32_t* __restrict__ n_dev, uint32_t cbits) {
     if (n_dev) n = min(n, *n_dev);
-    const uint32_t p = xcd_bid() * 256 + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t i = order[p];
-    // the slots around p, requested in the same round trip: a cell holds two or three particles, so the cell mates the ranking loop
-    // below looks at are almost always among them — and that loop's loads, which depend on the cell range (itself two dependent
-    // loads away), no longer are a round trip of their own
-    constexpr int RANK_WIN = 3;
-    uint32_t near[2 * RANK_WIN + 1];
+    const uint32_t b0 = xcd_bid() * 256;
+    if (b0 >= n) return;
+    const uint32_t p = b0 + threadIdx.x;
+    const bool live = p < n;
+    // The words of order[] around p: a cell holds three or four particles, so the cell mates the ranking below looks at are almost
+    // always among them — and so are the two ends of the cell (ORDER_HEAD; round 5: the cell index of the record and the cell's range
+    // in the fine table — two dependent round trips and 4 + 2.5 bytes of HBM traffic per particle — are only fetched by a lane whose
+    // cell reaches out of this window).  The workgroup's 256 words and eight on either side go through LDS: one load per lane instead
+    // of twelve, and the record's own loads below are in flight while they get there.
+    constexpr int RANK_L = 5, RANK_R = 6;  // a cell of up to six particles lies inside [p - 5, p + 6] with the head of the next one, whichever member p is
+    constexpr uint32_t ORD_HALO = 8;
+    static_assert(RANK_L <= (int)ORD_HALO && RANK_R <= (int)ORD_HALO, "window of order[] words in LDS");
+    __shared__ uint32_t sord[256 + 2 * ORD_HALO];
+    const uint32_t own = order[min(p, n - 1u)];
+    sord[ORD_HALO + threadIdx.x] = own;
+    if (threadIdx.x < 2 * ORD_HALO) {
+        // (below slot 0: copies of slot 0, a head; beyond n - 1: never looked at, the end test below is on the slot number)
+        const int32_t k = threadIdx.x < ORD_HALO ? (int32_t)(b0 + threadIdx.x) - (int32_t)ORD_HALO : (int32_t)(b0 + 256u + threadIdx.x - ORD_HALO);
+        sord[threadIdx.x < ORD_HALO ? threadIdx.x : 256u + threadIdx.x] = order[(uint32_t)min(max(k, 0), (int32_t)n - 1)];
+    }
+    const uint32_t i = own & ORDER_INDEX;
+    const bool ok = live && i < n_in;
+    // The record's words are requested HERE: what follows in a lane that needs the cell range is a chain of three dependent round
+    // trips the record's loads would otherwise queue behind.
+    const uint32_t ic = ok ? i : 0u;
+    float2 q = a.pos_in[ic];  // the record's position as it arrives at dst
+    const float2 v = a.vel_in ? a.vel_in[ic] : make_float2(0.0f, 0.0f);
+    const float r1 = a.r_in ? a.r_in[ic] : 0.0f, r2 = a.r2_in ? a.r2_in[ic] : 0.0f, r3 = a.r3_in ? a.r3_in[ic] : 0.0f;
+    uint32_t id = a.u_in ? a.u_in[ic] : 0u;
+    __syncthreads();
+    if (!ok) return;
+    uint32_t near[RANK_L + RANK_R + 1];
 #pragma unroll
-    for (int d = -RANK_WIN; d <= RANK_WIN; ++d) near[d + RANK_WIN] = order[(uint32_t)min(max((int32_t)p + d, 0), (int32_t)n - 1)];
-    if (i >= n_in) return;
-    // The record's words are requested HERE, together with its cell index: what follows (cell range, ranking loop) is a chain of three
-    // dependent round trips the record's loads would otherwise queue behind (the early returns keep the compiler from hoisting them).
-    const uint32_t ci = cidx[i];
-    float2 q = a.pos_in[i];  // the record's position as it arrives at dst
-    const float2 v = a.vel_in ? a.vel_in[i] : make_float2(0.0f, 0.0f);
-    const float r1 = a.r_in ? a.r_in[i] : 0.0f, r2 = a.r2_in ? a.r2_in[i] : 0.0f, r3 = a.r3_in ? a.r3_in[i] : 0.0f;
-    uint32_t id = a.u_in ? a.u_in[i] : 0u;
-    if (ci == EMPTY) return;
-    const uint2 se = fine[ci];
-    const uint32_t s = se.x;
-    uint32_t e = se.y;
-    if (e > n) e = n;
+    for (int d = -RANK_L; d <= RANK_R; ++d) near[d + RANK_L] = sord[(int)(ORD_HALO + threadIdx.x) + d];
+    // the cell's first slot: the nearest head at or below p (slot 0 is one); its end: the nearest head above p, or n
+    uint32_t heads_l = 0, heads_r = 0;
+#pragma unroll
+    for (int d = 0; d <= RANK_L; ++d) heads_l |= (near[RANK_L - d] >> 31) << d;
+#pragma unroll
+    for (int d = 1; d <= RANK_R; ++d) heads_r |= ((near[RANK_L + d] >> 31) | (p + (uint32_t)d >= n ? 1u : 0u)) << (d - 1);
     uint32_t dst;
-    if (e - s <= RANK_LOOP_MAX && a.rank_by_id && a.u_in) {
-        // (the tiling-invariant order: by persistent id; not the hot path — a test and comparison mode)
-        const uint32_t me = id & 0x7FFFFFFFu;
-        uint32_t rank = 0;
-        for (uint32_t k = s; k < e; ++k) {
-            const uint32_t j = order[k];
-            // (caller-supplied ids may repeat, sphx_multi_upload: equal ids keep their previous order, so every record still gets a slot
-            // of its own)
-            const uint32_t idj = j < n_in ? a.u_in[j] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-            rank += (j != i && (idj < me || (idj == me && j < i))) ? 1u : 0u;
-        }
-        dst = s + rank;
-    } else if (e - s <= RANK_LOOP_MAX) {
+    if (heads_l != 0u && heads_r != 0u && !(a.rank_by_id && a.u_in)) {
+        const uint32_t below = (uint32_t)__builtin_ctz(heads_l), above = (uint32_t)__builtin_ctz(heads_r) + 1u;  // the cell is [p - below, p + above)
         uint32_t rank = 0;
 #pragma unroll
-        for (int d = -RANK_WIN; d <= RANK_WIN; ++d) {
-            const int32_t k = (int32_t)p + d;
-            rank += (k >= (int32_t)s && k < (int32_t)e && near[d + RANK_WIN] < i) ? 1u : 0u;
+        for (int d = -RANK_L; d <= RANK_R; ++d) {
+            if (d == 0) continue;
+            const bool mate = d < 0 ? (uint32_t)(-d) <= below : (uint32_t)d < above;
+            rank += (mate && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
         }
-        // (whatever the cell holds outside the window)
-        for (uint32_t k = s; k + RANK_WIN < p && k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
-        for (uint32_t k = max(s, p + RANK_WIN + 1u); k < e; ++k) rank += (order[k] < i) ? 1u : 0u;
-        dst = s + rank;
+        dst = p - below + rank;
     } else {
-        // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
-        // stall the GPU for seconds.  Its particles stay in arrival order (a valid permutation of the cell's slots); reported.
-        dst = p;
-        if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
+        const uint32_t cw = cidx[i];
+        if (cw == EMPTY) return;
+        const uint2 se = fine[cw & ((1u << cbits) - 1u)];
+        const uint32_t s = se.x;
+        uint32_t e = se.y;
+        if (e > n) e = n;
+        if (e - s <= RANK_LOOP_MAX && a.rank_by_id && a.u_in) {
+            // (the tiling-invariant order: by persistent id; not the hot path — a test and comparison mode)
+            const uint32_t me = id & 0x7FFFFFFFu;
+            uint32_t rank = 0;
+            for (uint32_t k = s; k < e; ++k) {
+                const uint32_t j = order[k] & ORDER_INDEX;
+                // (caller-supplied ids may repeat, sphx_multi_upload: equal ids keep their previous order, so every record still gets a slot
+                // of its own)
+                const uint32_t idj = j < n_in ? a.u_in[j] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                rank += (j != i && (idj < me || (idj == me && j < i))) ? 1u : 0u;
+            }
+            dst = s + rank;
+        } else if (e - s <= RANK_LOOP_MAX) {
+            uint32_t rank = 0;
+#pragma unroll
+            for (int d = -RANK_L; d <= RANK_R; ++d) {
+                const int32_t k = (int32_t)p + d;
+                rank += (k >= (int32_t)s && k < (int32_t)e && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
+            }
+            // (whatever the cell holds outside the window)
+            for (uint32_t k = s; k + RANK_L < p && k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
+            for (uint32_t k = max(s, p + RANK_R + 1u); k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
+            dst = s + rank;
+        } else {
+            // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
+            // stall the GPU for seconds.  Its particles stay in arrival order (a valid permutation of the cell's slots); reported.
+            dst = p;
+            if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
+        }
     }
     if (dst >= n) return;
     if (a.vel_in) {
