@@ -465,36 +465,45 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * SCAN1_TILE;
     const uint32_t was_empty = tile_empty[bid];
-    uint32_t v[SCAN1_ITEMS];
-    uint32_t s = 0;
-    const uint32_t t0 = base + threadIdx.x * SCAN1_ITEMS;
-    const bool full = t0 + SCAN1_ITEMS <= len;
-    if (full) {
-        uint4* p4 = reinterpret_cast<uint4*>(in + t0);
+    // Round 5: STRIPED.  A wavefront owns a quarter of the tile; in trip k a lane holds the four consecutive entries
+    // wbase + 256 k + 4 lane .. + 3, so a load is one contiguous KiB per wavefront and a store of the ranges two half-dense
+    // instructions over the same 2 KiB.  (Blocked — sixteen consecutive entries per lane — every load touched a line per lane pair
+    // and every store a line per lane: 64 lines for 1 KiB.)  The price is one wave scan per trip instead of one.
+    constexpr uint32_t TRIPS = SCAN1_ITEMS / 4, WAVE_ITEMS = 64 * SCAN1_ITEMS;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wbase = base + w * WAVE_ITEMS + lane * 4u;
+    uint32_t v[TRIPS][4], incl[TRIPS], segtot[TRIPS];
 #pragma unroll
-        for (uint32_t k = 0; k < SCAN1_ITEMS / 4; ++k) {
-            const uint4 q = p4[k];
-            v[4 * k] = q.x;
-            v[4 * k + 1] = q.y;
-            v[4 * k + 2] = q.z;
-            v[4 * k + 3] = q.w;
-        }
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t t = wbase + k * 256u;
+        if (t + 4u <= len) {
+            uint4* const p4 = reinterpret_cast<uint4*>(in + t);
+            const uint4 q = *p4;
+            v[k][0] = q.x, v[k][1] = q.y, v[k][2] = q.z, v[k][3] = q.w;
+            if ((q.x | q.y | q.z | q.w) != 0u) *p4 = make_uint4(0, 0, 0, 0);  // the histogram is re-zeroed where it was not zero
+        } else {
 #pragma unroll
-        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) s += v[k];
-        if (s != 0u) {
-#pragma unroll
-            for (uint32_t k = 0; k < SCAN1_ITEMS / 4; ++k) p4[k] = make_uint4(0, 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) {
-            v[k] = (t0 + k < len) ? in[t0 + k] : 0;
-            if (t0 + k < len && v[k] != 0u) in[t0 + k] = 0;
-            s += v[k];
+            for (uint32_t c = 0; c < 4; ++c) {
+                v[k][c] = (t + c < len) ? in[t + c] : 0u;
+                if (t + c < len && v[k][c] != 0u) in[t + c] = 0u;
+            }
         }
     }
-    uint32_t total;
-    uint32_t run = block_excl_scan_256(s, &total);
+    uint32_t wtot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        incl[k] = wave_incl_scan((v[k][0] + v[k][1]) + (v[k][2] + v[k][3]));
+        segtot[k] = (uint32_t)__builtin_amdgcn_readlane((int)incl[k], 63);
+        wtot += segtot[k];
+    }
+    __shared__ uint32_t wsum_s[4];
+    if (lane == 0) wsum_s[w] = wtot;
+    __syncthreads();
+    uint32_t run = 0;  // the entries of this tile in front of this wavefront's quarter
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < w) run += wsum_s[k];
+    const uint32_t total = (wsum_s[0] + wsum_s[1]) + (wsum_s[2] + wsum_s[3]);
     const bool skip_out = total == 0u && was_empty != 0u;  // (workgroup-uniform)
     __shared__ uint32_t excl_s;
     if (threadIdx.x == 0) {
@@ -544,31 +553,29 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     // that is only right while a scan tile covers whole directory blocks)
     static_assert(SCAN1_TILE % BLOCK_CELLS == 0, "the tile_empty skip needs scan tiles made of whole directory blocks (SPHX_SCAN_ITEMS = 16)");
     if (skip_out) return;
-    if (full) {
-        uint4* o4 = reinterpret_cast<uint4*>(out + t0);  // two {start,end} entries per 16-byte store
 #pragma unroll
-        for (uint32_t k = 0; k < SCAN1_ITEMS / 2; ++k) {
-            uint4 q;
-            q.x = run;
-            run += v[2 * k];
-            q.y = run;
-            q.z = run;
-            run += v[2 * k + 1];
-            q.w = run;
-            o4[k] = q;
-        }
-    } else {
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t t = wbase + k * 256u;
+        uint32_t r[5];
+        r[0] = run + (incl[k] - ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])));
 #pragma unroll
-        for (uint32_t k = 0; k < SCAN1_ITEMS; ++k) {
-            if (t0 + k < len) out[t0 + k] = make_uint2(run, run + v[k]);
-            run += v[k];
+        for (uint32_t c = 0; c < 4; ++c) r[c + 1] = r[c] + v[k][c];
+        if (t + 4u <= len) {
+            uint4* const o4 = reinterpret_cast<uint4*>(out + t);  // two {start, end} entries per 16-byte store
+            o4[0] = make_uint4(r[0], r[1], r[1], r[2]);
+            o4[1] = make_uint4(r[2], r[3], r[3], r[4]);
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c)
+                if (t + c < len) out[t + c] = make_uint2(r[c], r[c + 1]);
         }
+        run += segtot[k];
     }
 }
 
-// what a kernel that ends with the re-grid's cell count (count_cell) is handed
 // the largest arrival slot count_cell's packed word can hold is one less: this value says "look in slot[]"
 __device__ __forceinline__ uint32_t cell_slot_max(uint32_t cbits) { return 0xFFFFFFFFu >> cbits; }
+// what a kernel that ends with the re-grid's cell count (count_cell) is handed
 struct CountArgs {
     GridView g;
     uint32_t *hist, *cidx, *slot;
