@@ -668,26 +668,24 @@ constexpr uint32_t ORDER_HEAD = 0x80000000u, ORDER_INDEX = 0x7FFFFFFFu;  // (con
 constexpr uint32_t SCATTER_PER_LANE = 4;
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
                                                   const uint2* __restrict__ fine, uint32_t* __restrict__ order, uint32_t cbits) {
-    const uint32_t i0 = (xcd_bid() * 256 + threadIdx.x) * SCATTER_PER_LANE;
-    if (i0 >= n) return;
+    // (lane t of a workgroup takes the particles b0 + t, b0 + 256 + t, ...: every load and every store of a wavefront is one run of
+    // consecutive words — particles arrive nearly sorted, so consecutive particles go to consecutive slots)
+    const uint32_t b0 = xcd_bid() * (256u * SCATTER_PER_LANE) + threadIdx.x;
+    if (b0 - threadIdx.x >= n) return;
     uint32_t w[SCATTER_PER_LANE];
-    if (i0 + SCATTER_PER_LANE <= n) {
-        const uint4 v = *(const uint4*)(cidx + i0);  // (hipMalloc'ed array, i0 a multiple of four)
-        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-    } else {
 #pragma unroll
-        for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = i0 + u < n ? cidx[i0 + u] : EMPTY;
-    }
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = b0 + u * 256u < n ? cidx[b0 + u * 256u] : EMPTY;
     uint32_t first[SCATTER_PER_LANE];
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) first[u] = fine[w[u] == EMPTY ? 0u : w[u] & ((1u << cbits) - 1u)].x;  // four gathers in flight
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) {
         if (w[u] == EMPTY) continue;
+        const uint32_t i = b0 + u * 256u;
         uint32_t sl = w[u] >> cbits;
-        if (sl == cell_slot_max(cbits)) sl = slot[i0 + u];
+        if (sl == cell_slot_max(cbits)) sl = slot[i];
         const uint32_t p = first[u] + sl;
-        if (p < n) order[p] = (i0 + u) | (sl == 0u ? ORDER_HEAD : 0u);
+        if (p < n) order[p] = i | (sl == 0u ? ORDER_HEAD : 0u);
     }
 }
 
@@ -718,6 +716,10 @@ struct GatherArgs {
     // so "previous index" means something else on every tile)
     uint32_t rank_by_id;
 };
+#ifndef SPHX_GATHER_PER_LANE
+#define SPHX_GATHER_PER_LANE 1
+#endif
+constexpr uint32_t GATHER_PER_LANE = SPHX_GATHER_PER_LANE;
 // a2+a3: neighborhood_search.rs:116-140.  Stable tie order: a particle's rank inside its cell is the number of cell mates
 // with a smaller previous index, so the result equals a stable sort by (cidx, previous index).
 // n = number of sorted slots; n_in = size of the unsorted input (larger than n when the tile path dropped particles).
@@ -727,116 +729,135 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
                                                       uint32_t n_in, const uint2* __restrict__ fine, GatherArgs a,
                                                       const uint32_t* __restrict__ n_dev, uint32_t cbits) {
     if (n_dev) n = min(n, *n_dev);
-    const uint32_t b0 = xcd_bid() * 256;
+    // GATHER_PER_LANE slots per lane (lane t: b0 + t, b0 + 256 + t, ...): the loads of all of them are requested before the first one
+    // is placed.  ONE is the default: unlike the scatter, whose lanes had a single 4-byte load each, this kernel has 24 bytes per slot
+    // in flight and moves its bytes at 5.3 TB/s with one slot per lane — 126 / 128 / 145 us at 16 M with one / two / four
+    // (profiles/r05_experiments/regrid.txt).
+    const uint32_t b0 = xcd_bid() * (256u * GATHER_PER_LANE);
     if (b0 >= n) return;
-    const uint32_t p = b0 + threadIdx.x;
-    const bool live = p < n;
     // The words of order[] around p: a cell holds three or four particles, so the cell mates the ranking below looks at are almost
     // always among them — and so are the two ends of the cell (ORDER_HEAD; round 5: the cell index of the record and the cell's range
     // in the fine table — two dependent round trips and 4 + 2.5 bytes of HBM traffic per particle — are only fetched by a lane whose
-    // cell reaches out of this window).  The workgroup's 256 words and eight on either side go through LDS: one load per lane instead
+    // cell reaches out of this window).  The workgroup's words and eight on either side go through LDS: one load per slot instead
     // of twelve, and the record's own loads below are in flight while they get there.
     constexpr int RANK_L = 5, RANK_R = 6;  // a cell of up to six particles lies inside [p - 5, p + 6] with the head of the next one, whichever member p is
-    constexpr uint32_t ORD_HALO = 8;
+    constexpr uint32_t ORD_HALO = 8, SPAN = 256u * GATHER_PER_LANE;
     static_assert(RANK_L <= (int)ORD_HALO && RANK_R <= (int)ORD_HALO, "window of order[] words in LDS");
-    __shared__ uint32_t sord[256 + 2 * ORD_HALO];
-    const uint32_t own = order[min(p, n - 1u)];
-    sord[ORD_HALO + threadIdx.x] = own;
+    __shared__ uint32_t sord[SPAN + 2 * ORD_HALO];
+    uint32_t own[GATHER_PER_LANE];
+#pragma unroll
+    for (uint32_t u = 0; u < GATHER_PER_LANE; ++u) {
+        own[u] = order[min(b0 + u * 256u + threadIdx.x, n - 1u)];
+        sord[ORD_HALO + u * 256u + threadIdx.x] = own[u];
+    }
     if (threadIdx.x < 2 * ORD_HALO) {
         // (below slot 0: copies of slot 0, a head; beyond n - 1: never looked at, the end test below is on the slot number)
-        const int32_t k = threadIdx.x < ORD_HALO ? (int32_t)(b0 + threadIdx.x) - (int32_t)ORD_HALO : (int32_t)(b0 + 256u + threadIdx.x - ORD_HALO);
-        sord[threadIdx.x < ORD_HALO ? threadIdx.x : 256u + threadIdx.x] = order[(uint32_t)min(max(k, 0), (int32_t)n - 1)];
+        const int32_t k = threadIdx.x < ORD_HALO ? (int32_t)(b0 + threadIdx.x) - (int32_t)ORD_HALO : (int32_t)(b0 + SPAN + threadIdx.x - ORD_HALO);
+        sord[threadIdx.x < ORD_HALO ? threadIdx.x : SPAN + threadIdx.x] = order[(uint32_t)min(max(k, 0), (int32_t)n - 1)];
     }
-    const uint32_t i = own & ORDER_INDEX;
-    const bool ok = live && i < n_in;
-    // The record's words are requested HERE: what follows in a lane that needs the cell range is a chain of three dependent round
-    // trips the record's loads would otherwise queue behind.
-    const uint32_t ic = ok ? i : 0u;
-    float2 q = a.pos_in[ic];  // the record's position as it arrives at dst
-    const float2 v = a.vel_in ? a.vel_in[ic] : make_float2(0.0f, 0.0f);
-    const float r1 = a.r_in ? a.r_in[ic] : 0.0f, r2 = a.r2_in ? a.r2_in[ic] : 0.0f, r3 = a.r3_in ? a.r3_in[ic] : 0.0f;
-    uint32_t id = a.u_in ? a.u_in[ic] : 0u;
+    // The records' words are requested HERE: what follows in a lane that needs the cell range is a chain of three dependent round
+    // trips the records' loads would otherwise queue behind.
+    bool ok[GATHER_PER_LANE];
+    float2 q[GATHER_PER_LANE], v[GATHER_PER_LANE];  // q: the record's position as it arrives at dst
+    float r1[GATHER_PER_LANE], r2[GATHER_PER_LANE], r3[GATHER_PER_LANE];
+    uint32_t id[GATHER_PER_LANE];
+#pragma unroll
+    for (uint32_t u = 0; u < GATHER_PER_LANE; ++u) {
+        const uint32_t i = own[u] & ORDER_INDEX;
+        ok[u] = b0 + u * 256u + threadIdx.x < n && i < n_in;
+        const uint32_t ic = ok[u] ? i : 0u;
+        q[u] = a.pos_in[ic];
+        v[u] = a.vel_in ? a.vel_in[ic] : make_float2(0.0f, 0.0f);
+        r1[u] = a.r_in ? a.r_in[ic] : 0.0f, r2[u] = a.r2_in ? a.r2_in[ic] : 0.0f, r3[u] = a.r3_in ? a.r3_in[ic] : 0.0f;
+        id[u] = a.u_in ? a.u_in[ic] : 0u;
+    }
     __syncthreads();
-    if (!ok) return;
-    uint32_t near[RANK_L + RANK_R + 1];
 #pragma unroll
-    for (int d = -RANK_L; d <= RANK_R; ++d) near[d + RANK_L] = sord[(int)(ORD_HALO + threadIdx.x) + d];
-    // the cell's first slot: the nearest head at or below p (slot 0 is one); its end: the nearest head above p, or n
-    uint32_t heads_l = 0, heads_r = 0;
+    for (uint32_t u = 0; u < GATHER_PER_LANE; ++u) {
+        if (!ok[u]) continue;
+        const uint32_t p = b0 + u * 256u + threadIdx.x, i = own[u] & ORDER_INDEX;
+        uint32_t near[RANK_L + RANK_R + 1];
 #pragma unroll
-    for (int d = 0; d <= RANK_L; ++d) heads_l |= (near[RANK_L - d] >> 31) << d;
+        for (int d = -RANK_L; d <= RANK_R; ++d) near[d + RANK_L] = sord[(int)(ORD_HALO + u * 256u + threadIdx.x) + d];
+        // the cell's first slot: the nearest head at or below p (slot 0 is one); its end: the nearest head above p, or n
+        uint32_t heads_l = 0, heads_r = 0;
 #pragma unroll
-    for (int d = 1; d <= RANK_R; ++d) heads_r |= ((near[RANK_L + d] >> 31) | (p + (uint32_t)d >= n ? 1u : 0u)) << (d - 1);
-    uint32_t dst;
-    if (heads_l != 0u && heads_r != 0u && !(a.rank_by_id && a.u_in)) {
-        const uint32_t below = (uint32_t)__builtin_ctz(heads_l), above = (uint32_t)__builtin_ctz(heads_r) + 1u;  // the cell is [p - below, p + above)
-        uint32_t rank = 0;
+        for (int d = 0; d <= RANK_L; ++d) heads_l |= (near[RANK_L - d] >> 31) << d;
 #pragma unroll
-        for (int d = -RANK_L; d <= RANK_R; ++d) {
-            if (d == 0) continue;
-            const bool mate = d < 0 ? (uint32_t)(-d) <= below : (uint32_t)d < above;
-            rank += (mate && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
-        }
-        dst = p - below + rank;
-    } else {
-        const uint32_t cw = cidx[i];
-        if (cw == EMPTY) return;
-        const uint2 se = fine[cw & ((1u << cbits) - 1u)];
-        const uint32_t s = se.x;
-        uint32_t e = se.y;
-        if (e > n) e = n;
-        if (e - s <= RANK_LOOP_MAX && a.rank_by_id && a.u_in) {
-            // (the tiling-invariant order: by persistent id; not the hot path — a test and comparison mode)
-            const uint32_t me = id & 0x7FFFFFFFu;
-            uint32_t rank = 0;
-            for (uint32_t k = s; k < e; ++k) {
-                const uint32_t j = order[k] & ORDER_INDEX;
-                // (caller-supplied ids may repeat, sphx_multi_upload: equal ids keep their previous order, so every record still gets a slot
-                // of its own)
-                const uint32_t idj = j < n_in ? a.u_in[j] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-                rank += (j != i && (idj < me || (idj == me && j < i))) ? 1u : 0u;
-            }
-            dst = s + rank;
-        } else if (e - s <= RANK_LOOP_MAX) {
+        for (int d = 1; d <= RANK_R; ++d) heads_r |= ((near[RANK_L + d] >> 31) | (p + (uint32_t)d >= n ? 1u : 0u)) << (d - 1);
+        uint32_t dst;
+        if (heads_l != 0u && heads_r != 0u && !(a.rank_by_id && a.u_in)) {
+            const uint32_t below = (uint32_t)__builtin_ctz(heads_l), above = (uint32_t)__builtin_ctz(heads_r) + 1u;  // the cell is [p - below, p + above)
             uint32_t rank = 0;
 #pragma unroll
             for (int d = -RANK_L; d <= RANK_R; ++d) {
-                const int32_t k = (int32_t)p + d;
-                rank += (k >= (int32_t)s && k < (int32_t)e && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
+                if (d == 0) continue;
+                const bool mate = d < 0 ? (uint32_t)(-d) <= below : (uint32_t)d < above;
+                rank += (mate && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
             }
-            // (whatever the cell holds outside the window)
-            for (uint32_t k = s; k + RANK_L < p && k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
-            for (uint32_t k = max(s, p + RANK_R + 1u); k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
-            dst = s + rank;
+            dst = p - below + rank;
         } else {
-            // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads would
-            // stall the GPU for seconds.  Its particles stay in arrival order (a valid permutation of the cell's slots); reported.
-            dst = p;
-            if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
+            const uint32_t cw = cidx[i];
+            if (cw == EMPTY) continue;
+            const uint2 se = fine[cw & ((1u << cbits) - 1u)];
+            const uint32_t s = se.x;
+            uint32_t e = se.y;
+            if (e > n) e = n;
+            if (e - s <= RANK_LOOP_MAX && a.rank_by_id && a.u_in) {
+                // (the tiling-invariant order: by persistent id; not the hot path — a test and comparison mode)
+                const uint32_t me = id[u] & 0x7FFFFFFFu;
+                uint32_t rank = 0;
+                for (uint32_t k = s; k < e; ++k) {
+                    const uint32_t j = order[k] & ORDER_INDEX;
+                    // (caller-supplied ids may repeat, sphx_multi_upload: equal ids keep their previous order, so every record still gets a
+                    // slot of its own)
+                    const uint32_t idj = j < n_in ? a.u_in[j] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                    rank += (j != i && (idj < me || (idj == me && j < i))) ? 1u : 0u;
+                }
+                dst = s + rank;
+            } else if (e - s <= RANK_LOOP_MAX) {
+                uint32_t rank = 0;
+#pragma unroll
+                for (int d = -RANK_L; d <= RANK_R; ++d) {
+                    const int32_t k = (int32_t)p + d;
+                    rank += (k >= (int32_t)s && k < (int32_t)e && (near[d + RANK_L] & ORDER_INDEX) < i) ? 1u : 0u;
+                }
+                // (whatever the cell holds outside the window)
+                for (uint32_t k = s; k + RANK_L < p && k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
+                for (uint32_t k = max(s, p + RANK_R + 1u); k < e; ++k) rank += ((order[k] & ORDER_INDEX) < i) ? 1u : 0u;
+                dst = s + rank;
+            } else {
+                // a cell no fluid cell looks like (a collapse to a point; strays parked in the table's first cell): occupancy^2 loads
+                // would stall the GPU for seconds.  Its particles stay in arrival order (a valid permutation of the cell's slots); reported.
+                dst = p;
+                if ((__hip_atomic_load(&a.flags->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DF_DENSE_CELL) == 0u) atomicOr(&a.flags->flags, DF_DENSE_CELL);
+            }
         }
-    }
-    if (dst >= n) return;
-    if (a.vel_in) {
-        if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
-            q.x = q.x + v.x * a.advect_dt;
-            q.y = q.y + v.y * a.advect_dt;
+        if (dst >= n) continue;
+        float2 qd = q[u];
+        if (a.vel_in) {
+            if (a.advect_dt > 0.0f && i < a.advect_below) {  // advect (dfsph.rs:499-510) applied while the record moves; same operations as in k_key_count<true>
+                qd.x = qd.x + v[u].x * a.advect_dt;
+                qd.y = qd.y + v[u].y * a.advect_dt;
+            }
+            a.vel_out[dst] = v[u];
         }
-        a.vel_out[dst] = v;
-    }
-    a.pos_out[dst] = q;
-    if (a.r_in) a.r_out[dst] = r1;
-    if (a.r2_in) a.r2_out[dst] = r2;
-    if (a.r3_in) a.r3_out[dst] = r3;
-    if (a.u_in) {
-        if (a.fix_owner && i < a.advect_below) {
-            const uint32_t cx = sat_u16((q.x - a.gmin_x) * a.cell_inv), cy = sat_u16((q.y - a.gmin_y) * a.cell_inv);  // cell_of()
-            if (!rect_has(a.own, cx, cy, 0u)) id &= 0x7FFFFFFFu;
-        }
-        a.u_out[dst] = id;
-        if (a.count_owned) {
-            const unsigned long long m = __ballot((id >> 31) != 0);
-            if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
-                atomicAdd(&a.count_owned->stripe[blockIdx.x % STRIPES].owned, (unsigned long long)__popcll(m));
+        a.pos_out[dst] = qd;
+        if (a.r_in) a.r_out[dst] = r1[u];
+        if (a.r2_in) a.r2_out[dst] = r2[u];
+        if (a.r3_in) a.r3_out[dst] = r3[u];
+        if (a.u_in) {
+            uint32_t idd = id[u];
+            if (a.fix_owner && i < a.advect_below) {
+                const uint32_t cx = sat_u16((qd.x - a.gmin_x) * a.cell_inv), cy = sat_u16((qd.y - a.gmin_y) * a.cell_inv);  // cell_of()
+                if (!rect_has(a.own, cx, cy, 0u)) idd &= 0x7FFFFFFFu;
+            }
+            a.u_out[dst] = idd;
+            if (a.count_owned) {
+                const unsigned long long m = __ballot((idd >> 31) != 0);
+                if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
+                    atomicAdd(&a.count_owned->stripe[blockIdx.x % STRIPES].owned, (unsigned long long)__popcll(m));
+            }
         }
     }
 }
