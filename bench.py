@@ -55,9 +55,9 @@ def bytes_per_particle_step_this_build(kbar, Id, Iv, Wd, Wv, rbar, compressed=Tr
     L = (2 + 4.0 / 64 + (8.0 / 6.0) * kbar + 4 * rbar + 4.0 / 256) if compressed else (8 + 4 * kbar)
     nonpressure = 16 + 4 + L + 8
     predict = (24 * min(Wd, 1.0) + 16 * (1.0 - min(Wd, 1.0))) if fuse_predict else 24
-    dens_iter_first = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 4 + 8)   # compute_error + correction (+ the re-grid's cell count: 8)
-    dens_iter_more = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 8 + 8)
-    regrid = 6 + 20 + 50                                                  # scan (per particle, dam-break table), scatter, gather
+    dens_iter_first = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 4 + 4)   # compute_error + correction (+ the re-grid's cell count: one word)
+    dens_iter_more = (16 + 4 + 4 + L + 4) + (16 + 12 + L + 8 + 8 + 4)
+    regrid = 6 + 10 + 44                                                  # scan (per particle, dam-break table), scatter, gather (round 5: 6 + 20 + 50 before)
     build = 8 + 8 + L + 4 + 4 + 4                                         # window of positions + velocities, lists out, density, alpha, k / velocity
     div_first = (0 if fuse_div else (16 + 4 + L + 4)) + (16 + 12 + L + 8 + 4)
     div_more = (16 + 4 + L + 4) + (16 + 12 + L + 8 + 8)
