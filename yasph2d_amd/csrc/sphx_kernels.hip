@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void slots9n(const NbGrid& g, uint32_t cx, uint32_t c
         }
     // A box that lies inside ONE 64 x 64 block (no cell of it on a block's rim) has all nine cells in that block's part of the table:
     // slot = offset | ly[dy] | lx[dx] ascends with dx and with dy, and the seven-comparator network sorts it.  Any lane on a rim
-    // (one wavefront in seven at 3.2 particles per cell): the full network for the wavefront.
+    // (36 % of the wavefronts of the dam break at t = 0, counted on the host): the full network for the wavefront.
     const bool inside = ((cx & 63u) - 1u) < 62u && ((cy & 63u) - 1u) < 62u;
     if (!__any(!inside))
         sort9_monotone(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
