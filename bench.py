@@ -517,12 +517,15 @@ def main():
             }
             vrec = valu_of(dominant, n) if dominant.startswith("neighbor_build") else None
             if vrec and vrec.get("active_inst_valu"):
-                # The neighbour build is bound by the vector instructions its wavefronts issue, not by its bytes: the
-                # HBM figures above stay (the contract's roofline), the binding resource is stated beside them — only when the committed SQ
-                # counters were taken from THESE kernels (kernel_source_sha256), otherwise the line says "hbm" and nothing about issue.
-                roof["bound"] = "valu"
-                roof["bound_note"] = ("the dominant kernel is bound by vector-instruction issue; achieved / peak / frac are its algorithmic bytes "
-                                      "against the HBM peak, as the bench contract prescribes")
+                # The neighbour build is far from its HBM roofline and NOT simply bound by vector issue either (DESIGN.md section 4,
+                # profiles/r05_experiments/build_phase_stamps.txt: +9 % / +18 % vector instructions cost +2.8 % / +3.3 % time): it sits at the
+                # knee between its vector time and the chain of round trips a wavefront waits for.  "bound" keeps the contract's roofline
+                # (rounds 3-4 said "valu" here); the issue-slot occupancy is stated beside it — only when the committed SQ counters were
+                # taken from THESE kernels (kernel_source_sha256).
+                roof["bound_note"] = ("the dominant kernel is co-limited by vector issue (slot occupancy below, an upper bound of the busy time: "
+                                      "~0.65 with the 2-cycle instruction classes counted as such) and by the dependent round trips of a "
+                                      "wavefront's life; a measured +9 % of vector instructions costs +2.8 % of its time.  achieved / peak / frac "
+                                      "are its algorithmic bytes against the HBM peak, as the bench contract prescribes")
                 roof["valu_issue_frac"] = vrec["active_inst_valu"] * 4.0 / (SIMDS * ENGINE_CLOCK_HZ * avg_ms * 1e-3)
                 roof["valu"] = {"insts_valu_per_wavefront": vrec["insts_valu_per_wave"], "wavefronts": vrec["waves"],
                                 "sq_active_inst_valu": vrec["active_inst_valu"], "simds": SIMDS, "engine_clock_hz": ENGINE_CLOCK_HZ,
