@@ -4,6 +4,8 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-also --prewarm-ms 0"
+# (one discarded run first: the first run of a call on a fresh box is 1-2 % slower than the following ones)
+timeout 400 $B --steps 10 --warmup 2 ${ABL_ARGS} > /dev/null 2>&1
 for v in "$@"; do
   if [ $v = base ]; then unset SPHX_LIB; else export SPHX_LIB=$GRAFT_REPO_ROOT/yasph2d_amd/variants/libsphx_$v.so; fi
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats16_$v -- $B --steps 10 --warmup 2 ${ABL_ARGS} > $out/stats16_$v.log 2>&1; echo "$v stats16 rc=$?"
