@@ -99,6 +99,40 @@ def test_boundary_replaced_mid_run():
     assert_bits_equal(bxy, o.boundary(), "sorted boundary")
 
 
+def test_boundary_grown_mid_run_keeps_the_old_tail_until_the_regrid():
+    """sphx_set_boundary with MORE particles than the arrays hold reallocates the [N|B] arrays between two steps.  The half step in
+    front of the next re-grid still walks the previous lists (dfsph.rs:436-497 run before update_neighborhood_datastructure, :512):
+    their static entries must find the previous boundary's records where they were (round-5 advisor finding: the tail was left
+    uninitialised and the FAST walk flag stayed set).  The scene is built so that the reference does the same thing: the boundary is
+    handed over in its sorted order (sorting it again is the identity) and the new particles are appended BEHIND it, so the old
+    static indices name the same particles in the new array."""
+    pos, boundary = dam_break(1.0)
+    ctx0 = y.SphxContext()
+    ctx0.set_boundary(boundary)
+    ctx0.upload(pos)
+    ctx0.update_neighborhood()
+    sorted_b, _ = ctx0.download_boundary()
+    ctx0.close()
+    ctx, o = pair(pos, sorted_b)
+    timer = y.TimeManager()
+    for _ in range(30):
+        step_both(ctx, o, timer)
+    bxy, _ = ctx.download_boundary()
+    assert_bits_equal(bxy, sorted_b, "a sorted boundary stays as it is")
+    xs = np.arange(0.3, 1.7, 0.01, dtype=np.float32)
+    shelf = np.stack([xs, np.full_like(xs, np.float32(0.35))], -1)  # a shelf across the tank, in the fluid's way
+    b2 = np.concatenate([sorted_b, shelf, shelf + np.float32([0.0, 0.01])]).astype(np.float32)
+    assert len(b2) > len(sorted_b)
+    ctx.set_boundary(b2)
+    o.set_boundary(b2)
+    for s in range(40):
+        step_both(ctx, o, timer)
+        if s in (0, 1, 39):
+            compare_state(ctx, o, f"step {s} after the boundary grew")
+    bxy, _ = ctx.download_boundary()
+    assert_bits_equal(bxy, o.boundary(), "sorted boundary")
+
+
 def test_fixed_time_step():
     pos, boundary = dam_break(1.0)
     ctx, o = pair(pos, boundary)

@@ -1411,11 +1411,13 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
             for (uint32_t u = 0; u < 4; ++u) {
                 if (fm[u] == 0ull) continue;  // (scalar)
                 const uint32_t gb = w0b + E[u];  // 8 g
+#ifndef SPHX_ABL_NOFAR2  // (timing experiments: the second loop does NOT re-read out-of-window records — results are wrong)
                 if (FUSE && far[u]) {
                     rj[u] = *(const float2*)((const char*)posA + gb);
                     if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
                     if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
                 }
+#endif
                 if (cap != 0u && staged) {
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm[u], run));
                     run += (uint32_t)__popcll(fm[u]);
@@ -1682,6 +1684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         pj[W - 1] = make_float2(p23.z, p23.w);
                     }
                 }
+#ifndef SPHX_ABL_NOFAR1  // (timing experiments: out-of-window candidates are NOT re-read from global memory — results are wrong)
                 if (ab >= far_lim) {
                     // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL of them from
                     // global memory (one address, loads with immediate offsets; what the window holds is the same data, and the
@@ -1690,6 +1693,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #pragma unroll
                     for (uint32_t u = 0; u < W; ++u) pj[u] = gp[u];
                 }
+#endif
                 bool acc[W];
 #pragma unroll
                 for (uint32_t u = 0; u < W; ++u) {
@@ -1713,12 +1717,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 a[0] = ta;
 #pragma unroll
                 for (uint32_t u = 0; u < W; ++u) a[u + 1] = a[u] + (acc[u] ? ROW_B : 0u);
+#ifdef SPHX_ABL_NOAPPEND  // (timing experiments: accepted candidates are counted, not stored — results are wrong)
+                if (false) {
+#else
                 if (!__any(ta > t_fast)) {
+#endif
 #pragma unroll
                     for (uint32_t u = 0; u < W; ++u) lds_store_u32(a[u], ab + 8u * u);
                 } else {
+#ifndef SPHX_ABL_NOAPPEND
 #pragma unroll
                     for (uint32_t u = 0; u < W; ++u) lds_store_u32(a[u] < t_end ? a[u] : t_dump, ab + 8u * u);
+#endif
                     if (a[W] > t_end) {  // rare: rows past the staged ones live in global memory (32-bit slots, at their wide address)
 #pragma unroll
                         for (uint32_t u = 0; u < W; ++u) {
