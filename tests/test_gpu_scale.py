@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full single-GPU size (1 M particles) and of the grid-directory growth path."""
+"""GPU tests at BASELINE.json's full single-GPU sizes (configs[1] = 1 M, configs[2] = 16 M particles) and of the grid-directory growth path."""
 import numpy as np
 import pytest
 from util import assert_bits_equal, assert_same_neighbors, brute_force_neighbors, dam_break
@@ -43,6 +43,96 @@ def test_one_million_particles_three_steps_bit_exact():
         f2, c2 = o.cells(static)
         np.testing.assert_array_equal(c1, c2)
         np.testing.assert_array_equal(f1, f2)
+
+
+def _compare_full(ctx, o, what, solver_state=False):
+    d = ctx.download()
+    assert_bits_equal(d["pos"], o.positions(), what + " positions")
+    assert_bits_equal(d["vel"], o.velocities(), what + " velocities")
+    assert_bits_equal(d["density"], o.densities(), what + " densities")
+    np.testing.assert_array_equal(d["ids"], o.ids())
+    del d
+    if solver_state:
+        ss = ctx.download_solver_state()
+        assert_bits_equal(ss["kappa"], o.kappa(), what + " kappa")
+        assert_bits_equal(ss["stiffness"], o.stiffness(), what + " stiffness (warm start of the divergence loop)")
+        del ss
+    ca, sa, la = ctx.download_neighbors()
+    cb, sb, lb = o.neighbors()
+    np.testing.assert_array_equal(ca, cb)  # NeighborRange counts {dynamic, total} of every particle
+    np.testing.assert_array_equal(sa, sb)
+    assert la.shape == lb.shape and np.array_equal(la, lb), what + " neighbour lists"  # (every entry, not a digest: 0.5 GB each at 16 M)
+    del ca, sa, la, cb, sb, lb
+    for static in (False, True):
+        f1, c1 = ctx.download_cells(static)
+        f2, c2 = o.cells(static)
+        np.testing.assert_array_equal(c1, c2)
+        np.testing.assert_array_equal(f1, f2)
+
+
+def test_sixteen_million_two_steps_bit_exact():
+    """configs[2] — the size the bench line is quoted on — against the oracle (its OpenMP build: ~5 s per step on the GPU box's host
+    cores), two steps from t = 0: dt in ns, vmax through it, iteration counts, positions, velocities, densities, ids, neighbour
+    counts and lists, cells.  k_neighbor_build<1> (warm-up) and <2>, the four walks and the re-grid at the headline size."""
+    pos, boundary = dam_break(float(np.sqrt(16.0e6 / 4050.0)))
+    assert 15_900_000 < len(pos) < 16_100_000
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    o = Oracle(omp=True)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    del pos
+    timer = y.TimeManager()
+    for s in range(2):
+        st, dt_ns = step(ctx, timer)
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns(), s
+        for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence", "neighbor_entries"):
+            assert st[k] == so[k], (s, k, st[k], so[k])
+    _compare_full(ctx, o, "16 M, step 2")
+
+
+def test_sixteen_million_disturbed_state_with_divergence_warm_start():
+    """The regime the 16 M scene spends steps ~2 000-3 400 in (bench.py's `also` window): the device runs 2 500 steps, its positions
+    and velocities are handed to a FRESH context and to the oracle, and both step in lock step.  There the divergence loop needs two
+    iterations and starts with a warm start (dfsph.rs:354-360): k_neighbor_build<3> and k_compute_error<true, false> against the
+    oracle at the headline size (they had only met it below 40 k particles), plus the warm-start stiffness itself."""
+    scale = float(np.sqrt(16.0e6 / 4050.0))
+    w = y.FluidParticleWorld()
+    w.reset_fluid(scale)
+    boundary = w.boundary_particles.copy()
+    solver = y.DFSPHSolver(w)
+    tm = y.TimeManager()
+    done = 0
+    while done < 2500:
+        solver.simulation_steps(w, tm, 250, sync_world=False)
+        done += 250
+    solver.sync_world(w)
+    pos, vel = w.positions.copy(), w.velocities.copy()
+    solver.close()
+    tm.close()
+    w.close()
+    assert np.isfinite(pos).all() and np.isfinite(vel).all()
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos, vel)
+    o = Oracle(omp=True)
+    o.set_boundary(boundary)
+    o.set_particles(pos, vel)
+    del pos, vel
+    timer = y.TimeManager()
+    warm = iv2 = 0
+    for s in range(5):
+        st, dt_ns = step(ctx, timer)
+        so = o.dfsph_step()
+        assert dt_ns == o.timer_step_ns(), s
+        for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence", "neighbor_entries"):
+            assert st[k] == so[k], (s, k, st[k], so[k])
+        warm += st["warmstart_divergence"]
+        iv2 += st["divergence_iterations"] >= 2
+    assert iv2 >= 4 and warm >= 3, (iv2, warm)  # the regime is the one meant: two divergence iterations, warm start firing
+    _compare_full(ctx, o, "16 M disturbed, step 5", solver_state=True)
 
 
 @pytest.mark.parametrize("target,steps", [(1.0e6, 60), (16.0e6, 20)])

@@ -1121,9 +1121,23 @@ __device__ unsigned long long g_stamp[16];
         __builtin_amdgcn_sched_barrier(0);                                                              \
         if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[15], 1ull);                                     \
     }
+// how long a wavefront waits for loads it has in flight at this point (vmcnt(0)): cycles -> g_stamp[k], occurrences -> g_stamp[k + 1];
+// may sit in divergent code (the first active lane reports)
+#define SPHX_STAMP_VMWAIT(k)                                                                            \
+    {                                                                                                   \
+        unsigned long long t0_, t1_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");                     \
+        if ((blockIdx.x & 63) == 5 && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) { \
+            atomicAdd(&g_stamp[k], t1_ - t0_);                                                          \
+            atomicAdd(&g_stamp[(k) + 1], 1ull);                                                         \
+        }                                                                                               \
+    }
 #else
 #define SPHX_STAMP(k)
 #define SPHX_STAMP_BEGIN()
+#define SPHX_STAMP_VMWAIT(k)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1416,6 +1430,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                     rj[u] = *(const float2*)((const char*)posA + gb);
                     if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
                     if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
+                    SPHX_STAMP_VMWAIT(12)
                 }
 #endif
                 if (cap != 0u && staged) {
@@ -1627,6 +1642,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     // block lies outside the directory's rectangle (a stray: its centre look-up was clamped) is given the benefit of the doubt
     const bool maybe_static = (centre & DIRN_FLAG) != 0u || (cx >> BLOCK_SHIFT) - gd.bx0 > gd.nbx1 || (cy >> BLOCK_SHIFT) - gd.by0 > gd.nby1;
     ranges9n(gd, slot, s, e);
+    const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
+    const uint32_t far_lim = wlen_b > 24u ? wlen_b - 24u : 0u;  // a trip starting at or beyond this byte offset (or below the window) leaves the window
+    const uint32_t nw0b = 0u - w0b;
+    // Round 6: the candidates of a cell that lies outside the window come from global memory — a round trip IN the candidate scan, with
+    // nothing else to do for the wavefront (about half the trips have such a lane: profiles/r06_experiments/far_prefetch.txt, -89 us of
+    // 559 at 16 M without them).  They are now requested ONE CELL AHEAD: the first cell's here, in front of the barrier, cell t + 1's at
+    // the head of cell t's trip — a trip lasts ~1 300 cycles of wall time with eight wavefronts sharing the SIMD, longer than the round
+    // trip.  far_first(t): this lane's first (four-wide) trip of cell t reads global memory (same test as in the trip itself).
+    float2 G[4];
+    auto far_first = [&](int t) { return ((s[t] << 3) + nw0b >= far_lim) & (s[t] != e[t]); };
+    auto prefetch = [&](int t) {
+        if (far_first(t)) {
+            const float2* const gp = (const float2*)((const char*)posA + (s[t] << 3));
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) G[u] = gp[u];
+        }
+    };
+#ifndef SPHX_NO_FAR_PREFETCH
+    if (scan) prefetch(0);
+#endif
 #pragma unroll
     for (uint32_t u = 0; u < NWIN; ++u)
         if (threadIdx.x + u * 256u < wlen) {
@@ -1639,7 +1674,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     __syncthreads();
     SPHX_STAMP(0)
     uint32_t ct = 0;
-    const uint32_t wlen_b = wlen * 8u, w0b = w0 * 8u;
     if (scan) {
         // phase 1: filter
         SPHX_STAMP(1)
@@ -1651,8 +1685,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const uint32_t t_end = t_base + STAGE_ROWS * ROW_B, t_fast = t_base + (STAGE_ROWS - 4u) * ROW_B;  // t_end: one past the lane's last staged row
         const uint32_t t_dump = lds_addr(&sm.dump[lane]);
         uint32_t ta = t_base;
-        const uint32_t far_lim = wlen_b > 24u ? wlen_b - 24u : 0u;  // a trip starting at or beyond this byte offset (or below the window) leaves the window
-        const uint32_t nw0b = 0u - w0b;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // Candidates of one cell, FOUR per trip.  (One candidate per trip — the round-1 form — spent most of its time on the trip
@@ -1669,8 +1701,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             // of a cell with five or six particles — the wavefront makes that trip when ANY of its lanes has such a cell, i.e. always
             // once the fluid is compressed (3.7 particles per cell after the impact, 1.9 trips per cell and wavefront with four-wide
             // trips only) — goes in two-wide trips at 24 instead of 42 vector instructions.
-            auto trip = [&](auto width) {
+            auto trip = [&](auto width, auto first_trip) {
                 constexpr uint32_t W = decltype(width)::value;
+                constexpr bool FIRST = decltype(first_trip)::value != 0;  // the cell's first trip: its out-of-window candidates were requested a cell ago (G)
                 const uint32_t rem = eb - ab;  // bytes of candidates left in this cell (>= 8)
                 const char* const base = (const char*)win + min(ab, wlen_b);  // below or beyond the window: the pad slots
                 float2 pj[W];
@@ -1685,6 +1718,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     }
                 }
 #ifndef SPHX_ABL_NOFAR1  // (timing experiments: out-of-window candidates are NOT re-read from global memory — results are wrong)
+#ifndef SPHX_NO_FAR_PREFETCH
+                if (FIRST) {
+                    if (ab >= far_lim) {
+                        SPHX_STAMP_VMWAIT(8)
+#pragma unroll
+                        for (uint32_t u = 0; u < W; ++u) pj[u] = G[u];
+                    }
+                    if (t < 8) prefetch(t + 1);  // (G is free again)
+                } else
+#endif
                 if (ab >= far_lim) {
                     // the first (ab "negative": j < w0) or the last of the four lies outside the window: this lane takes ALL of them from
                     // global memory (one address, loads with immediate offsets; what the window holds is the same data, and the
@@ -1692,6 +1735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     const float2* const gp = (const float2*)((const char*)posA + (w0b + ab));
 #pragma unroll
                     for (uint32_t u = 0; u < W; ++u) pj[u] = gp[u];
+                    SPHX_STAMP_VMWAIT(10)
                 }
 #endif
                 bool acc[W];
@@ -1741,9 +1785,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 ab = (uint32_t)min((int32_t)(ab + 8u * W), (int32_t)eb);
             };
             if (ab != eb) {
-                trip(std::integral_constant<uint32_t, 4>{});
-                while (ab != eb) trip(std::integral_constant<uint32_t, 2>{});
+                trip(std::integral_constant<uint32_t, 4>{}, std::integral_constant<int, 1>{});
+                while (ab != eb) trip(std::integral_constant<uint32_t, 2>{}, std::integral_constant<int, 0>{});
             }
+#ifndef SPHX_NO_FAR_PREFETCH
+            else if (t < 8)
+                prefetch(t + 1);  // (an empty cell makes no trip: the next cell's request goes out from here)
+#endif
         }
         ct = (ta - t_base) / ROW_B;
 #endif
