@@ -502,7 +502,9 @@ def main():
             avg_ms = max(avg_raw - infl, 1e-6)
             ach = live["bytes"] / live["launches"] / (avg_ms * 1e-3) / 1e9
             roof = {
-                "bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                # `bound` names what the evidence says limits the dominant kernel (round-5 review, item 6): a kernel far below its HBM roofline
+                # is not "hbm"-bound.  frac stays the contract's figure: algorithmic bytes against the HBM peak (`roofline_of_frac`).
+                "bound": "hbm" if ach / HBM_PEAK_GBS >= 0.5 else "latency+issue", "roofline_of_frac": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_achievable_6300": ach / HBM_ACHIEVABLE_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "avg_launch_ms_bracketed": avg_raw,
                 "bracket_inflation_ms": infl, "empty_event_bracket_ms": ev_ms, "launches": live["launches"],
@@ -515,17 +517,34 @@ def main():
                 "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (which keeps kernels from overlapping their "
                         "neighbours' tails): its sum exceeds ms_per_step; information only",
             }
+            # Whole-step ledger per kernel: HBM bytes per launch from the committed counter passes of THESE kernels (hash-gated like
+            # `traffic`), launch duration and launches per step live from this run's every-launch pass (event-inflated, see note).
+            ledger = {}
+            for kname, v in sorted(prof.items()):
+                kb, _ = traffic_of(kname, n)
+                if not v["launches"]:
+                    continue
+                us = max(v["total_ms"] / v["launches"] - infl, 1e-6) * 1e3
+                ledger[kname] = {"launches_per_step": v["launches"] / extra, "us_per_launch": us,
+                                 "hbm_bytes_per_launch": kb, "tb_per_s": (kb / (us * 1e-6) / 1e12) if kb else None,
+                                 "algorithmic_bytes_per_launch": v["bytes"] / v["launches"] if v.get("bytes") else None}
+            roof["per_kernel"] = ledger
+            roof["per_kernel_note"] = ("us_per_launch: hipEvent brackets around every launch of a separate pass outside the timed region, minus "
+                                       "bracket_inflation_ms; hbm_bytes_per_launch: FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the committed "
+                                       "rocprofv3 --pmc passes (traffic_source), null when those were taken from other kernel sources")
+            if roof["bound"] != "hbm":
+                roof["bound_note"] = ("the dominant kernel is co-limited by vector issue (slot occupancy ~0.9, ~0.65 of the SIMD time with the 2-cycle "
+                                      "instruction classes counted as such) and by the dependent round trips of a wavefront's life: +9 % vector "
+                                      "instructions cost +2.8 % of its time (round 5), -5 500 cycles of waiting per wavefront buy 2 %, fewer "
+                                      "instructions in more trips lose 7 % (round 6, profiles/r06_experiments/far_prefetch.txt).  achieved / peak / "
+                                      "frac are its algorithmic bytes against the HBM peak, as the bench contract prescribes")
             vrec = valu_of(dominant, n) if dominant.startswith("neighbor_build") else None
             if vrec and vrec.get("active_inst_valu"):
                 # The neighbour build is far from its HBM roofline and NOT simply bound by vector issue either (DESIGN.md section 4,
                 # profiles/r05_experiments/build_phase_stamps.txt: +9 % / +18 % vector instructions cost +2.8 % / +3.3 % time): it sits at the
-                # knee between its vector time and the chain of round trips a wavefront waits for.  "bound" keeps the contract's roofline
-                # (rounds 3-4 said "valu" here); the issue-slot occupancy is stated beside it — only when the committed SQ counters were
-                # taken from THESE kernels (kernel_source_sha256).
-                roof["bound_note"] = ("the dominant kernel is co-limited by vector issue (slot occupancy below, an upper bound of the busy time: "
-                                      "~0.65 with the 2-cycle instruction classes counted as such) and by the dependent round trips of a "
-                                      "wavefront's life; a measured +9 % of vector instructions costs +2.8 % of its time.  achieved / peak / frac "
-                                      "are its algorithmic bytes against the HBM peak, as the bench contract prescribes")
+                # knee between its vector time and the chain of round trips a wavefront waits for (rounds 3-4 said "valu" in `bound`, round 5
+                # "hbm"; since round 6 it says "latency+issue" while frac < 0.5).  The issue-slot occupancy is stated beside it — only when the
+                # committed SQ counters were taken from THESE kernels (kernel_source_sha256).
                 roof["valu_issue_frac"] = vrec["active_inst_valu"] * 4.0 / (SIMDS * ENGINE_CLOCK_HZ * avg_ms * 1e-3)
                 roof["valu"] = {"insts_valu_per_wavefront": vrec["insts_valu_per_wave"], "wavefronts": vrec["waves"],
                                 "sq_active_inst_valu": vrec["active_inst_valu"], "simds": SIMDS, "engine_clock_hz": ENGINE_CLOCK_HZ,
@@ -720,6 +739,7 @@ def main():
     prewarm(args.particles)
     scale, w = scene_of(args.particles * world)
     pos, boundary = w.positions, w.boundary_particles
+    t_scene_done = time.perf_counter()
     n_global = len(pos)
     diam = np.float32(2.0) * np.float32(w.properties()["particle_radius"])
     timer = y.TimeManager()
@@ -854,6 +874,15 @@ def main():
                 "particles_total": n_global,
                 "transport": minfo["transport"],
                 "setup_seconds": setup_seconds,
+                "setup_breakdown_seconds": {"imports_rendezvous_and_global_scene_build": t_scene_done - t_process_start,
+                                            "solver_create_boundary_and_upload": setup_seconds - (t_scene_done - t_process_start),
+                                            "of_which_ownership_pass_over_the_global_scene_in_libsphx": minfo.get("ownership_seconds")},
+                # what one halo exchange moves out of this rank (all peers together): `packed` = (1 + records) * 32 B per peer as counted on
+                # the device, `sent` = what ncclSend was given (packed rounded up to 64 KiB when the record counts travel first —
+                # SPHX_EXACT_EXCHANGE, default for messages >= 1 MiB at capacity — else the buffers' capacity; packed is 0 then: not known)
+                "halo_bytes_per_step_per_rank": {"packed": minfo["halo_bytes_packed"] / max(1, minfo["exchanges"]),
+                                                 "sent": minfo["halo_bytes_sent"] / max(1, minfo["exchanges"]),
+                                                 "capacity_per_peer": (1 + minfo["cap_records"]) * 32},
                 "parallelism":
                 f"{world} spatial tiles ({'columns cut again across (2 x N/2)' if minfo['grid_layout'] else 'strips along ' + 'xy'[max(minfo['axis'], 0)]}, cut at "
                 f"particle-count quantiles), step loop inside libsphx (sphx_multi), ghost halo {minfo['halo_now']} of <= {args.halo} cells (follows "

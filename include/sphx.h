@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define SPHX_ABI_VERSION 4 /* 4: sphx_set_tiling_invariant
+#define SPHX_ABI_VERSION 5 /* 5: sphx_shm_allgather, sphx_tile_send_counts, sphx_multi_info_t.halo_bytes_{packed,sent} / .ownership_seconds (appended)
+                            * 4: sphx_set_tiling_invariant
                             * 2: sphx_step_stats.remote_entries, sphx_multi_*, frame-loop calls, sphx_sub_regrid_{div,warm}, SPHX_FLAG_DENSE_CELL
                             * 3: sphx_comm_ops.abort, sphx_multi_info_t list statistics, sphx_shm_abort (and sphx_shm_open as a collective),
                             *    sphx_build_stats, sphx_sub_run_ahead, sphx_tile_carry_warmstart, sphx_tile_defer_advect, sphx_sub_predict_iteration, sphx_tile_band_packs,
@@ -272,6 +273,10 @@ int sphx_tile_defer_advect(sphx_ctx* ctx, int on);
  * correction — send counts per workgroup, kept / retired, cell count (SPHX_TILE_FUSE_CLASS=0 turns that off) — and only visited
  * the workgroups that send something. */
 int sphx_tile_band_packs(const sphx_ctx* ctx, uint32_t* out);
+/* The record counts in the headers of the send buffers the last sphx_tile_pack_n / sphx_tile_advect_pack_n filled (clamped to
+ * cap_records), on the host: waits for the packing kernels (one small device-to-host copy per peer).  The caller may then move
+ * (1 + out_counts[k]) * 32 bytes per peer instead of the buffers' capacity. */
+int sphx_tile_send_counts(sphx_ctx* ctx, void* const* d_send, uint32_t n_send, uint32_t cap_records, uint32_t* out_counts);
 int sphx_sub_nonpressure(sphx_ctx* ctx, float dt_prev, float* out_vmax_sq); /* dfsph.rs:436-477; max over OWNED particles */
 int sphx_sub_predict(sphx_ctx* ctx, float dt);                             /* dfsph.rs:484-492 */
 int sphx_sub_warmstart(sphx_ctx* ctx, int divergence, float dt);           /* dfsph.rs:199-205 / :354-360 */
@@ -321,6 +326,10 @@ typedef struct sphx_multi_info_t {
     uint64_t build_particles, neighbor_entries, remote_entries;
     uint64_t owned_local; /* particles the local tiles own */
     char transport[96];
+    /* tile 0's halo exchanges so far, bytes it sent to all its peers together: what its packing pass filled ((1 + records) * 32 per
+     * peer) and what travelled (the same rounded up to 64 KiB when the record counts were exchanged first, else the buffers' capacity) */
+    uint64_t halo_bytes_packed, halo_bytes_sent;
+    double ownership_seconds; /* set-up, tile 0: cell, owner and send-band count of every particle of the global scene (host threads) */
 } sphx_multi_info_t;
 int sphx_multi_default_options(sphx_multi_options* out);
 /* all tiles in this process: tile r runs on HIP device devices[r] (a device may appear more than once); one host thread per tile */
@@ -371,6 +380,10 @@ sphx_shm* sphx_shm_open(const char* name, int rank, int world);
  * SPHX_ERR_NOT_READY — on every waiting rank, at once — when a rank has called sphx_shm_abort / sphx_shm_close instead of arriving, or
  * after SPHX_SHM_TIMEOUT_S seconds (default 300) without it. */
 int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out);
+/* every rank's n <= 8 doubles to every rank: out[r * n + k] = rank r's in[k] (world * n doubles).  Same failure behaviour.  The tile
+ * driver publishes the record counts of its halo messages this way, so that ncclSend / ncclRecv move what was packed, not the
+ * buffers' capacity. */
+int sphx_shm_allgather(sphx_shm* h, const double* in, int n, double* out);
 void sphx_shm_abort(sphx_shm* h); /* this rank has failed: release the ranks that wait for it */
 void sphx_shm_close(sphx_shm* h);
 

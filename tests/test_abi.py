@@ -29,7 +29,7 @@ def test_binding_table_covers_header(sphx_lib):
 
 
 def test_abi_version(sphx_lib):
-    assert sphx_lib.sphx_abi_version() == 4
+    assert sphx_lib.sphx_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -357,12 +357,23 @@ def _shm_worker(rank, world, name, q):
         buf_in[1] = 0.1 * (rank + 1) + it
         assert L.sphx_shm_allreduce(h, buf_in, 2, it & 1, buf_out) == 0
         res.append((buf_out[0], buf_out[1]))
+    # the all-gather the halo exchange publishes its per-peer record counts with (round 6), interleaved with all-reduces
+    gat = (C.c_double * (8 * world))()
+    rows = []
+    for it in range(500):
+        for k in range(8):
+            buf_in[k] = float(rank * 100 + k * 7 + it)
+        assert L.sphx_shm_allgather(h, buf_in, 8, gat) == 0
+        rows.append([gat[j] for j in range(8 * world)])
+        if it % 3 == 0:
+            assert L.sphx_shm_allreduce(h, buf_in, 1, 0, buf_out) == 0
     L.sphx_shm_close(h)
-    q.put((rank, res))
+    q.put((rank, (res, rows)))
 
 
 def test_shm_allreduce_four_processes():
-    """sphx_shm_allreduce: every rank gets identical bits, combined in rank order, for 2000 back-to-back rounds of alternating ops."""
+    """sphx_shm_allreduce: every rank gets identical bits, combined in rank order, for 2000 back-to-back rounds of alternating ops;
+    sphx_shm_allgather: every rank gets every rank's row, 500 rounds interleaved with all-reduces."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -386,7 +397,11 @@ def test_shm_allreduce_four_processes():
                 sa, sb = sa + a[r], sb + b[r]
             want = (sa, sb)
         for r in range(world):
-            assert got[r][it] == want
+            assert got[r][0][it] == want
+    for it in range(500):
+        want_rows = [float(r * 100 + k * 7 + it) for r in range(world) for k in range(8)]
+        for r in range(world):
+            assert got[r][1][it] == want_rows
 
 
 def _shm_victim_worker(rank, world, name, q, die_at, mode):

@@ -7,6 +7,6 @@ for v in "${vs[@]}"; do
   export SPHX_LIB=$GRAFT_REPO_ROOT/yasph2d_amd/variants/libsphx_$v.so
   for P in "${ps[@]}"; do
     timeout 300 python3 bench.py --steps 20 --warmup 2 --particles $P --no-cpu-baseline --no-also --no-roofline --prewarm-ms 0 ${STAMP_ARGS} > $out/bench_${v}_$P.json 2> $out/bench_${v}_$P.err
-    echo "$v $P: $(grep SPHX_STAMPS $out/bench_${v}_$P.err | tail -1)"
+    echo "$v $P: $(grep SPHX_STAMPS $out/bench_${v}_$P.err | tail -4 | tr "\n" " ")"
   done
 done

@@ -98,7 +98,8 @@ class SphxMultiInfo(C.Structure):
     _fields_ = [("world", C.c_uint32), ("local_tiles", C.c_uint32), ("halo_now", C.c_uint32), ("halo_max", C.c_uint32), ("peers", C.c_uint32),
                 ("n_local", C.c_uint32), ("cap_records", C.c_uint32), ("grid_layout", C.c_uint32), ("axis", C.c_int32), ("band_packs", C.c_uint32),
                 ("exchanges", C.c_uint64), ("rebalances", C.c_uint64), ("build_particles", C.c_uint64), ("neighbor_entries", C.c_uint64),
-                ("remote_entries", C.c_uint64), ("owned_local", C.c_uint64), ("transport", C.c_char * 96)]
+                ("remote_entries", C.c_uint64), ("owned_local", C.c_uint64), ("transport", C.c_char * 96),
+                ("halo_bytes_packed", C.c_uint64), ("halo_bytes_sent", C.c_uint64), ("ownership_seconds", C.c_double)]
 
 
 LAYOUT_AUTO, LAYOUT_STRIPS, LAYOUT_GRID = 0, 1, 2
@@ -149,9 +150,11 @@ SIGNATURES = {
     "sphx_sub_iteration": (_i, [_vp, _i, _f, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "sphx_sub_predict_iteration": (_i, [_vp, _f, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "sphx_tile_band_packs": (_i, [_vp, C.POINTER(_u32)]),
+    "sphx_tile_send_counts": (_i, [_vp, _vp, _u32, _u32, C.POINTER(_u32)]),
     "sphx_sub_advect": (_i, [_vp, _f]),
     "sphx_shm_open": (_vp, [C.c_char_p, _i, _i]),
     "sphx_shm_allreduce": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sphx_shm_allgather": (_i, [_vp, _vp, _i, _vp]),
     "sphx_shm_abort": (None, [_vp]),
     "sphx_sub_run_ahead": (_i, [_vp, C.c_float]),
     "sphx_tile_carry_warmstart": (_i, [_vp, _i, _i]),

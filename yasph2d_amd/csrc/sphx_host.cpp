@@ -756,8 +756,8 @@ void sphx_shm_abort(sphx_shm* h) {
     if (h && h->seg) h->seg->abort.store(1, std::memory_order_release);
 }
 
-int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out) {
-    if (!h || !in || !out || n < 1 || n > SHM_MAX_N) return SPHX_ERR_INVALID_ARGUMENT;
+// one meeting of all ranks: this rank's n <= 8 doubles go into its slot; returns once every rank's are there (buffer index in *buf)
+static int shm_meet(sphx_shm* h, const double* in, int n, int* buf_out) {
     ShmSegment* s = h->seg;
     const int buf = (int)(h->epoch & 1);
     for (int k = 0; k < n; ++k) s->slots[buf][h->rank][k] = in[k];
@@ -778,6 +778,16 @@ int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out
         }
         __builtin_ia32_pause();
     }
+    *buf_out = buf;
+    return SPHX_OK;
+}
+
+int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out) {
+    if (!h || !in || !out || n < 1 || n > SHM_MAX_N) return SPHX_ERR_INVALID_ARGUMENT;
+    int buf;
+    const int rc = shm_meet(h, in, n, &buf);
+    if (rc) return rc;
+    ShmSegment* s = h->seg;
     for (int k = 0; k < n; ++k) {
         double acc = s->slots[buf][0][k];
         for (int r = 1; r < h->world; ++r) {
@@ -786,6 +796,18 @@ int sphx_shm_allreduce(sphx_shm* h, const double* in, int n, int op, double* out
         }
         out[k] = acc;
     }
+    return SPHX_OK;
+}
+
+// every rank's n doubles to every rank: out[r * n + k] = rank r's in[k] (the halo exchange's per-peer record counts travel this way)
+int sphx_shm_allgather(sphx_shm* h, const double* in, int n, double* out) {
+    if (!h || !in || !out || n < 1 || n > SHM_MAX_N) return SPHX_ERR_INVALID_ARGUMENT;
+    int buf;
+    const int rc = shm_meet(h, in, n, &buf);
+    if (rc) return rc;
+    ShmSegment* s = h->seg;
+    for (int r = 0; r < h->world; ++r)
+        for (int k = 0; k < n; ++k) out[r * n + k] = s->slots[buf][r][k];
     return SPHX_OK;
 }
 

@@ -196,6 +196,7 @@ struct Mailbox {
     volatile uint32_t loop_gen_done;  // generation number of the loop that has finished
     uint32_t loop_iters;              // ... after this many iterations
     double loop_hist[LOOP_HIST];      // residual sum of iteration k of the running loop at [k % LOOP_HIST] (the host re-derives every decision)
+    uint32_t send_counts[MAX_TILE_PEERS];  // sphx_tile_send_counts: landing place of the headers' record counts (host copies, no kernel writes here)
 };
 
 // A solver loop (dfsph.rs:195-247 / :346-402) whose termination test runs on the device: the last workgroup of compute_error
@@ -364,6 +365,7 @@ struct sphx_ctx {
     uint32_t tile_class_n = 0, tile_class_dt_bits = 0;
     bool tile_fix_owner = false;    // the re-grid's gather clears the owner bit of kept particles that left the own rectangle
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
+    int fuse_warm = 1;             // SPHX_FUSE_WARM=0: the divergence warm start is never folded into the neighbour build (A/B)
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it
     bool div_warm_fused = false;   // the latest neighbour build applied the divergence loop's warm start
     int host_loop = 0;        // SPHX_HOST_LOOP=1: the host judges every residual (round-1 behaviour; A/B runs)

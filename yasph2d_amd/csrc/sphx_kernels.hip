@@ -1103,14 +1103,14 @@ __global__ __launch_bounds__(256) void k_fill_tails(const float2* __restrict__ b
 // In-kernel stamps (diagnostic builds only, -DSPHX_STAMPS: tools/ab_build.sh): cycles per phase, summed over wavefronts.  The
 // stamp values leave the kernel through g_stamp only; no result is computed from them.
 #ifdef SPHX_STAMPS
-__device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_stamp[4][16];  // [MODE of the build][slot]
 #define SPHX_STAMP(k)                                                                                   \
     {                                                                                                   \
         unsigned long long t_;                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[k], t_ - stamp_prev_);                          \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[MODE][k], t_ - stamp_prev_);                          \
         stamp_prev_ = t_;                                                                               \
     }
 #define SPHX_STAMP_BEGIN()                                                                              \
@@ -1119,7 +1119,7 @@ __device__ unsigned long long g_stamp[16];
         __builtin_amdgcn_sched_barrier(0);                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev_)::"memory");             \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[15], 1ull);                                     \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stamp[MODE][15], 1ull);                                     \
     }
 // how long a wavefront waits for loads it has in flight at this point (vmcnt(0)): cycles -> g_stamp[k], occurrences -> g_stamp[k + 1];
 // may sit in divergent code (the first active lane reports)
@@ -1130,8 +1130,8 @@ __device__ unsigned long long g_stamp[16];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory");                     \
         if ((blockIdx.x & 63) == 5 && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) { \
-            atomicAdd(&g_stamp[k], t1_ - t0_);                                                          \
-            atomicAdd(&g_stamp[(k) + 1], 1ull);                                                         \
+            atomicAdd(&g_stamp[MODE][k], t1_ - t0_);                                                          \
+            atomicAdd(&g_stamp[MODE][(k) + 1], 1ull);                                                         \
         }                                                                                               \
     }
 #else
@@ -1429,7 +1429,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                 if (FUSE && far[u]) {
                     rj[u] = *(const float2*)((const char*)posA + gb);
                     if (DIV) vj[u] = *(const float2*)((const char*)dv.vel + gb);  // boundary records carry v = 0 (the static form of dfsph.rs:274 is v_i alone)
-                    if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail; static entries do not use it
+                    if (WARM) wj4[u] = gat(dv.warm, (gb >> 3) < soff ? (gb >> 3) : i);  // warm[] has no boundary tail (clamped below, once the trip's gathers are all out)
                     SPHX_STAMP_VMWAIT(12)
                 }
 #endif
@@ -1442,6 +1442,15 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                         lds_store_u32(ta + u * ROW_B, (r << 3) + ((rbase << 3) | 1u));
                     }
                 }
+            }
+            if (WARM) {
+                // A gathered warm-start value becomes k_j like the staged ones; a static entry's k_j is 0 — its term is k_i alone
+                // (dfsph.rs:339), and k_i + 0 = k_i to the bit (k_i = -0 would become +0: the sign of a zero summand never reaches the
+                // sum, which starts from +0; k_correct does the same) — so the walk adds (k_i + k_j) for every entry without a
+                // "dynamic or static?" select.  Behind the loop above: in it, the arithmetic would wait for each gather in turn.
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (far[u]) wj4[u] = ((w0b + E[u]) >> 3) < soff ? 0.5f * fmaxf(wj4[u], dv.lim) : 0.0f;
             }
         }
         if (FUSE) {
@@ -1466,9 +1475,8 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
                         const f32x2 dvg = (vi2 - f32x2{vj[u].x, vj[u].y}) * sgd;
                         delta = delta + (dvg.x + dvg.y);
                     }
-                    if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339)
-                        const float kj = 0.5f * fmaxf(wj4[u], dv.lim);
-                        const float sk = k0 + u < cd ? ki + kj : ki;
+                    if (WARM) {  // (ki + kj) for dynamic neighbours, ki alone for static ones (dfsph.rs:335 / :339: staged as kj = 0)
+                        const float sk = ki + wj4[u];
                         ws = ws + f32x2{sk, sk} * sgd;
                     }
                 }
@@ -1667,7 +1675,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         if (threadIdx.x + u * 256u < wlen) {
             win[threadIdx.x + u * 256u] = wreg[u];
             if (MODE == 2) vwin[threadIdx.x + u * 256u] = vreg[u];
-            if (MODE == 3) swin[threadIdx.x + u * 256u] = sreg[u];
+            // (MODE 3: the window holds k_j = 0.5 max(warm_j, lim) — the clamp of dfsph.rs:356-358 applied ONCE per staged record, by the
+            // same two operations the walk applied per neighbour until round 5)
+            if (MODE == 3) swin[threadIdx.x + u * 256u] = 0.5f * fmaxf(sreg[u], dv.lim);
         }
     // pad slots: a candidate read past the window's end finds a NaN position (rejected) until the re-read from global memory replaces it
     if (threadIdx.x < WIN_PAD) win[wlen + threadIdx.x] = make_float2(__uint_as_float(0x7FC00000u), 0.0f);

@@ -34,6 +34,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <array>
+#include <chrono>
 #include <vector>
 
 #include "../../include/sphx.h"
@@ -142,9 +144,22 @@ struct Layout {
 struct Comm {
     int rank = 0, world = 1;
     virtual ~Comm() {}
-    // send[k] -> peers[k], recv[k] <- peers[k]; `bytes` of each buffer; ordered on the tile's stream (no host synchronisation)
-    virtual int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) = 0;
+    // send[k] -> peers[k] (sbytes[k] of it), recv[k] <- peers[k] (rbytes[k]); ordered on the tile's stream (no host synchronisation)
+    virtual int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, const std::vector<size_t>& sbytes,
+                         const std::vector<size_t>& rbytes, hipStream_t st) = 0;
     virtual int allreduce(const double* in, int n, int op, double* out) = 0;  // op 0 sum, 1 max; same bits on every rank
+    // every rank's 8 doubles to every rank (out: world * 8).  Default: one all-reduce per rank (sums of one value and zeros: exact).
+    virtual int allgather8(const double* in, double* out) {
+        for (int r = 0; r < world; ++r) {
+            double v[8];
+            for (int k = 0; k < 8; ++k) v[k] = r == rank ? in[k] : 0.0;
+            const int rc = allreduce(v, 8, 0, out + (size_t)r * 8);
+            if (rc) return rc;
+        }
+        return SPHX_OK;
+    }
+    // can this transport move fewer bytes than the buffers hold?  (the caller-supplied function table has ONE size for all peers)
+    virtual bool sized_messages() const { return true; }
     virtual void abort() {}  // this tile has failed: the tiles waiting for it in an all-reduce are released (they fail too)
     // the run is poisoned (a queued receive may never complete): tear the transport down WITHOUT waiting for what is enqueued on it
     virtual void abandon() {}
@@ -158,10 +173,12 @@ struct CallbackComm : Comm {
         rank = o.rank;
         world = o.world;
     }
-    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, const std::vector<size_t>& sbytes,
+                 const std::vector<size_t>&, hipStream_t st) override {
         if (peers.empty()) return SPHX_OK;
-        return ops.exchange(ops.user, peers.data(), (int)peers.size(), send.data(), recv.data(), bytes, (void*)st);
+        return ops.exchange(ops.user, peers.data(), (int)peers.size(), send.data(), recv.data(), sbytes[0], (void*)st);  // (all sizes are the capacity)
     }
+    bool sized_messages() const override { return false; }
     int allreduce(const double* in, int n, int op, double* out) override { return ops.allreduce(ops.user, in, n, op, out); }
     void abort() override {
         if (ops.abort) ops.abort(ops.user);
@@ -289,13 +306,14 @@ struct RcclComm : Comm {
         }
         if (shm) sphx_shm_close(shm);
     }
-    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, const std::vector<size_t>& sbytes,
+                 const std::vector<size_t>& rbytes, hipStream_t st) override {
         if (peers.empty()) return SPHX_OK;
         if (!comm) return SPHX_ERR_NOT_READY;
         int rc = p_gstart();
         for (size_t k = 0; k < peers.size() && !rc; ++k) {
-            rc = p_send(send[k], bytes, /*ncclUint8*/ 1, peers[k], comm, st);
-            if (!rc) rc = p_recv(recv[k], bytes, 1, peers[k], comm, st);
+            rc = p_send(send[k], sbytes[k], /*ncclUint8*/ 1, peers[k], comm, st);
+            if (!rc) rc = p_recv(recv[k], rbytes[k], 1, peers[k], comm, st);
         }
         const int rc2 = p_gend();
         if (rc || rc2) {
@@ -305,6 +323,7 @@ struct RcclComm : Comm {
         return SPHX_OK;
     }
     int allreduce(const double* in, int n, int op, double* out) override { return sphx_shm_allreduce(shm, in, n, op, out); }
+    int allgather8(const double* in, double* out) override { return sphx_shm_allgather(shm, in, 8, out); }
     const char* name() const override { return "RCCL send/recv (halo records) + shared-memory all-reduce (scalars)"; }
 };
 
@@ -363,7 +382,8 @@ struct LocalComm : Comm {
         hipEventDestroy(sh->slot[rank].packed);
         hipEventDestroy(sh->slot[rank].drained);
     }
-    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, size_t bytes, hipStream_t st) override {
+    int exchange(const std::vector<int>& peers, const std::vector<void*>& send, const std::vector<void*>& recv, const std::vector<size_t>&,
+                 const std::vector<size_t>& rbytes, hipStream_t st) override {
         if (world == 1) return SPHX_OK;
         LocalShared::Slot& me = sh->slot[rank];
         me.peers = peers;
@@ -377,7 +397,7 @@ struct LocalComm : Comm {
                 if (p.peers[j] == rank) src = p.send[j];
             if (!src) return SPHX_ERR_INVALID_ARGUMENT;
             if (hipStreamWaitEvent(st, p.packed, 0) != hipSuccess) return SPHX_ERR_HIP;
-            if (hipMemcpyPeerAsync(recv[k], device, src, p.device, bytes, st) != hipSuccess) return SPHX_ERR_HIP;
+            if (hipMemcpyPeerAsync(recv[k], device, src, p.device, rbytes[k], st) != hipSuccess) return SPHX_ERR_HIP;
         }
         if (hipEventRecord(me.drained, st) != hipSuccess) return SPHX_ERR_HIP;
         if (!sh->barrier()) return SPHX_ERR_NOT_READY;  // everybody's copies are queued ...
@@ -398,6 +418,18 @@ struct LocalComm : Comm {
             for (int r = 1; r < world; ++r) acc = op == 1 ? std::max(acc, sh->slot[r].val[k]) : acc + sh->slot[r].val[k];  // rank order: same bits everywhere
             out[k] = acc;
         }
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;
+        return SPHX_OK;
+    }
+    int allgather8(const double* in, double* out) override {
+        if (world == 1) {
+            for (int k = 0; k < 8; ++k) out[k] = in[k];
+            return SPHX_OK;
+        }
+        for (int k = 0; k < 8; ++k) sh->slot[rank].val[k] = in[k];
+        if (!sh->barrier()) return SPHX_ERR_NOT_READY;
+        for (int r = 0; r < world; ++r)
+            for (int k = 0; k < 8; ++k) out[(size_t)r * 8 + k] = sh->slot[r].val[k];
         if (!sh->barrier()) return SPHX_ERR_NOT_READY;
         return SPHX_OK;
     }
@@ -422,6 +454,13 @@ struct TileDriver {
     uint32_t num_density_iters = 1, num_divergence_iters = 0;  // dfsph.rs:51,55
     uint32_t cap = 0;
     uint64_t exchanges = 0, rebalances = 0, steps = 0;
+    uint64_t halo_bytes_packed = 0, halo_bytes_sent = 0;  // to all peers together, over all exchanges
+    double ownership_seconds = 0.0;  // set-up: cells, owner and send-band counts of the global scene (host threads)
+    int exact_exchange = -1;  // SPHX_EXACT_EXCHANGE: 1 always, 0 never, -1 (default) when a message at capacity is >= EXACT_MIN_BYTES
+    // where the record counts have to travel first (a host wait for the packing kernels + one meeting of the ranks, ~20 us) only
+    // messages that are worth it do: at 1 M particles per tile a strip's message is 0.3 MB at capacity (2 us on a link), at the 16 M
+    // per tile of configs[3] / [4] it is 11 MB
+    static constexpr size_t EXACT_MIN_BYTES = 1u << 20;
     const uint32_t boundary_margin = 256;
     double valid = INF, kvalid = INF, avalid = INF;
     Rect rect{}, clip_rect{};
@@ -495,6 +534,7 @@ struct TileDriver {
         comm = std::move(c);
         overlap = O.overlap_exchange != 0;
         if (const char* e = std::getenv("SPHX_MULTI_OVERLAP")) overlap = e[0] == '1';
+        if (const char* e = std::getenv("SPHX_EXACT_EXCHANGE")) exact_exchange = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
         if (const char* e = std::getenv("SPHX_RUN_AHEAD")) run_ahead_ok = e[0] != '0';
         halo_max = O.halo_cells ? O.halo_cells : 16;
         min_halo = std::min<uint32_t>(6, halo_max);
@@ -574,47 +614,94 @@ struct TileDriver {
     int setup(const Layout& lay, const float* pos, const float* vel, const uint32_t* ids, uint32_t n, const float* bnd, uint32_t nb) {
         layout = lay;
         if (layout.world() != comm->world) return fail(SPHX_ERR_INVALID_ARGUMENT, "layout and communicator disagree about the number of tiles");
+        // Every rank is handed the GLOBAL scene (128 M particles at configs[4]): cells, bounding box, owner and send-band counts of all of
+        // them — O(n W) — run on up to 8 host threads over contiguous slices (round 6; one thread took ~7 s of the set-up at 128 M).
+        // Slices are merged in slice order: `mine` stays ascending, the counts are sums — the result does not depend on the thread count.
+        const auto t_own0 = std::chrono::steady_clock::now();
         std::vector<uint32_t> cx(n), cy(n);
         uint32_t x0 = 0xFFFFFFFFu, x1 = 0, y0 = 0xFFFFFFFFu, y1 = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            cx[i] = cell_coord(pos[2 * i], grid_min[0], cell_inv);
-            cy[i] = cell_coord(pos[2 * i + 1], grid_min[1], cell_inv);
-            x0 = std::min(x0, cx[i]);
-            x1 = std::max(x1, cx[i]);
-            y0 = std::min(y0, cy[i]);
-            y1 = std::max(y1, cy[i]);
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8u, std::max(1u, std::thread::hardware_concurrency()), (uint64_t)n / 65536u + 1u}));
+        auto slices = [&](auto&& body) {  // body(t, i0, i1)
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { body(t, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T)); });
+            body(0u, 0u, (uint32_t)((uint64_t)n / T));
+            for (auto& x : th) x.join();
+        };
+        {
+            std::vector<std::array<uint32_t, 4>> bb(T, std::array<uint32_t, 4>{0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u});
+            slices([&](unsigned t, uint32_t i0, uint32_t i1) {
+                std::array<uint32_t, 4> b = bb[t];
+                for (uint32_t i = i0; i < i1; ++i) {
+                    cx[i] = cell_coord(pos[2 * (size_t)i], grid_min[0], cell_inv);
+                    cy[i] = cell_coord(pos[2 * (size_t)i + 1], grid_min[1], cell_inv);
+                    b[0] = std::min(b[0], cx[i]);
+                    b[1] = std::max(b[1], cx[i]);
+                    b[2] = std::min(b[2], cy[i]);
+                    b[3] = std::max(b[3], cy[i]);
+                }
+                bb[t] = b;
+            });
+            for (const auto& b : bb) {
+                x0 = std::min(x0, b[0]);
+                x1 = std::max(x1, b[1]);
+                y0 = std::min(y0, b[2]);
+                y1 = std::max(y1, b[3]);
+            }
         }
         int rc = place();
         if (rc) return rc;
         const auto rects = layout.rects();
         const int W = comm->world;
         std::vector<uint32_t> mine;
+        std::vector<std::vector<uint32_t>> mine_t(T);
         if (O.cap_records) {
             cap = O.cap_records;
-            for (uint32_t i = 0; i < n; ++i)
-                if (in_rect(cx[i], cy[i], rect)) mine.push_back(i);
+            slices([&](unsigned t, uint32_t i0, uint32_t i1) {
+                for (uint32_t i = i0; i < i1; ++i)
+                    if (in_rect(cx[i], cy[i], rect)) mine_t[t].push_back(i);
+            });
         } else {
             // particles a tile has to send to one peer: estimate from the global scene, with head-room for compression waves
-            std::vector<uint64_t> cnt((size_t)W * W, 0);
             std::vector<uint8_t> touch((size_t)W * W, 0);
             for (int a = 0; a < W; ++a)
                 for (int b = 0; b < W; ++b) touch[(size_t)a * W + b] = a != b && rects_touch(rects[a], rects[b], halo_max);
-            for (uint32_t i = 0; i < n; ++i) {
-                int a = -1;
-                for (int r = 0; r < W; ++r)
-                    if (in_rect(cx[i], cy[i], rects[r])) {
-                        a = r;
-                        break;
+            std::vector<std::vector<uint64_t>> cnt_t(T, std::vector<uint64_t>((size_t)W * W, 0));
+            slices([&](unsigned t, uint32_t i0, uint32_t i1) {
+                std::vector<uint64_t>& cnt = cnt_t[t];
+                int last = 0;  // (neighbouring particles of the scene mostly share their owner: try that rectangle first)
+                for (uint32_t i = i0; i < i1; ++i) {
+                    int a = -1;
+                    if (in_rect(cx[i], cy[i], rects[last])) {
+                        a = last;
+                    } else {
+                        for (int r = 0; r < W; ++r)
+                            if (in_rect(cx[i], cy[i], rects[r])) {
+                                a = r;
+                                break;
+                            }
                     }
-                if (a < 0) continue;
-                if (a == comm->rank) mine.push_back(i);
-                for (int b = 0; b < W; ++b)
-                    if (touch[(size_t)a * W + b] && in_rect(cx[i], cy[i], rects[b], halo_max)) cnt[(size_t)a * W + b] += 1;
-            }
+                    if (a < 0) continue;
+                    last = a;
+                    if (a == comm->rank) mine_t[t].push_back(i);
+                    for (int b = 0; b < W; ++b)
+                        if (touch[(size_t)a * W + b] && in_rect(cx[i], cy[i], rects[b], halo_max)) cnt[(size_t)a * W + b] += 1;
+                }
+            });
             uint64_t near = 0;
-            for (uint64_t c : cnt) near = std::max(near, c);
+            for (size_t k = 0; k < (size_t)W * W; ++k) {
+                uint64_t c = 0;
+                for (unsigned t = 0; t < T; ++t) c += cnt_t[t][k];
+                near = std::max(near, c);
+            }
             cap = (uint32_t)std::max<uint64_t>(1024, (uint64_t)(near * 1.5) + 1024);
         }
+        {
+            size_t tot = 0;
+            for (const auto& m : mine_t) tot += m.size();
+            mine.reserve(tot);
+            for (const auto& m : mine_t) mine.insert(mine.end(), m.begin(), m.end());
+        }
+        ownership_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_own0).count();
         const uint64_t n_own = mine.size();
         if (sphx_num_particles(ctx)) {
             // a fresh decomposition of an edited scene: the tile starts from an empty particle set (the slot-bound warm-start values of
@@ -685,12 +772,47 @@ struct TileDriver {
         // latency hides behind interior work.  Off by default: with all tiles on ONE GPU (the only hardware this was measured on) the
         // two cross-stream event hand-offs cost more than the overlapped 8 us of counting (0.47 vs 0.40 ms/step, 2 x 500 k particles);
         // whether it pays over xGMI has to be measured on a multi-GPU node.
+        // Round 6: the messages carry what was PACKED.  The packing pass leaves each message's record count in its header on the device;
+        // the host fetches the counts (sphx_tile_send_counts: it waits for the packing kernels), the ranks tell each other (one meeting
+        // at the shared segment: every rank's <= 8 counts to every rank), and ncclSend / ncclRecv move (1 + records) * 32 bytes rounded
+        // up to 64 KiB instead of the buffers' capacity (1.5 x the estimate of the set-up + 1 024 records).  Capacity buffers unchanged:
+        // a count beyond the capacity is clamped on both sides, k_tile_apply raises DF_HALO_CAP as before.
+        std::vector<size_t> sbytes(peers.size(), bytes), rbytes(peers.size(), bytes);
+        const bool exact = !peers.empty() && comm->sized_messages() && (exact_exchange == 1 || (exact_exchange < 0 && bytes >= EXACT_MIN_BYTES));
+        if (exact) {
+            uint32_t cnt[SPHX_MAX_TILE_PEERS] = {0};
+            TCHK(sphx_tile_send_counts(ctx, send.data(), (uint32_t)send.size(), c, cnt));
+            double row[8] = {0}, all[8 * 64];
+            if (comm->world > 64) return fail(SPHX_ERR_INVALID_ARGUMENT, "more than 64 tiles");
+            for (size_t k = 0; k < peers.size(); ++k) row[k] = (double)cnt[k];
+            rc = comm->allgather8(row, all);
+            if (rc) return fail(rc, "halo exchange failed (record counts)");
+            const auto rects = layout.rects();
+            auto round64k = [&](uint64_t records) { return std::min<size_t>(bytes, (((size_t)(1 + records) * HALO_RECORD + 65535u) >> 16) << 16); };
+            for (size_t k = 0; k < peers.size(); ++k) {
+                // my place in peer p's list of peers: p built it the way place() builds mine (ascending ranks that touch its rectangle)
+                const int p = peers[k];
+                int idx = 0, mine = -1;
+                for (int q = 0; q < comm->world; ++q)
+                    if (q != p && rects_touch(rects[p], rects[q], halo_max)) {
+                        if (q == comm->rank) mine = idx;
+                        idx += 1;
+                    }
+                if (mine < 0 || mine >= 8) return fail(SPHX_ERR_INVALID_ARGUMENT, "halo exchange: the peer relation is not symmetric");
+                sbytes[k] = round64k(cnt[k]);
+                rbytes[k] = round64k((uint64_t)std::min<double>(all[(size_t)p * 8 + mine], (double)c));
+                halo_bytes_packed += (uint64_t)(1 + cnt[k]) * HALO_RECORD;
+                halo_bytes_sent += sbytes[k];
+            }
+        } else {
+            halo_bytes_sent += (uint64_t)bytes * peers.size();  // (what was packed is not known to the host on this path)
+        }
         if (!peers.empty() && !overlap) {
-            rc = comm->exchange(peers, send, recv, bytes, stream);
+            rc = comm->exchange(peers, send, recv, sbytes, rbytes, stream);
             if (rc) return fail(rc, "halo exchange failed");
         } else if (!peers.empty()) {
             if (hipEventRecord(ev_packed, stream) != hipSuccess || hipStreamWaitEvent(comm_stream, ev_packed, 0) != hipSuccess) return fail(SPHX_ERR_HIP, "event (pack -> exchange)");
-            rc = comm->exchange(peers, send, recv, bytes, comm_stream);
+            rc = comm->exchange(peers, send, recv, sbytes, rbytes, comm_stream);
             if (rc) return fail(rc, "halo exchange failed");
             if (hipEventRecord(ev_exchanged, comm_stream) != hipSuccess) return fail(SPHX_ERR_HIP, "event (exchange -> unpack)");
             TCHK(sphx_tile_count_kept(ctx));
@@ -1191,6 +1313,9 @@ int sphx_multi_info(const sphx_multi* m, sphx_multi_info_t* out) {
     out->halo_max = t.halo_max;
     out->peers = (uint32_t)t.peers.size();
     out->exchanges = t.exchanges;
+    out->halo_bytes_packed = t.halo_bytes_packed;
+    out->halo_bytes_sent = t.halo_bytes_sent;
+    out->ownership_seconds = t.ownership_seconds;
     out->rebalances = t.rebalances;
     sphx_tile_band_packs(t.ctx, &out->band_packs);
     out->n_local = t.n_local;
