@@ -88,6 +88,34 @@ def test_in_process_2x2_through_the_impact_bit_exact_vs_reference_loop(overlap):
     assert info["exchanges"] == o[0][2] and info["rebalances"] == final[0][1] > 3 and info["grid_layout"] == 1
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_halo_messages_carry_what_was_packed(exact, monkeypatch):
+    """Round 6: with the record counts exchanged first (SPHX_EXACT_EXCHANGE=1; the default for messages of >= 1 MiB at capacity) a halo
+    message is (1 + records) * 32 bytes rounded up to 64 KiB, not the buffers' capacity — same results either way, bit for bit."""
+    monkeypatch.setenv("SPHX_EXACT_EXCHANGE", exact)
+    pos, boundary = dam_break(2.0)
+    world, axis, halo, steps = 3, 1, 10, 40
+    cuts = quantile_cuts(cell_coord(pos, axis), world)
+    o, _ = oracle_tiles(pos, boundary, world, axis, steps, halo=halo, fixed=(2, 2), cuts=cuts, adaptive_halo=True, rebalance_every=0)
+    m = MultiSolver(y.default_params(fixed_iterations=(2, 2)), devices=[0] * world, halo=halo, rebalance_every=0)
+    m.set_strips(axis, cuts)
+    m.set_boundary(boundary)
+    m.upload(pos)
+    timer = y.TimeManager()
+    stats = [m.step(timer) for _ in range(steps)]
+    compare(m.download(), o, stats, o[0][1])
+    info = m.info()
+    ex, peers, cap_bytes = info["exchanges"], info["peers"], (1 + info["cap_records"]) * 32
+    assert ex >= steps and peers >= 1
+    if exact == "1":
+        assert 0 < info["halo_bytes_packed"] <= info["halo_bytes_sent"] <= ex * peers * cap_bytes
+        assert info["halo_bytes_sent"] - info["halo_bytes_packed"] < ex * peers * 65536  # rounded up to 64 KiB per message
+        assert info["halo_bytes_sent"] < 0.9 * ex * peers * cap_bytes  # the capacity is 1.5 x the set-up's estimate + 1024 records
+    else:
+        assert info["halo_bytes_packed"] == 0 and info["halo_bytes_sent"] <= ex * peers * cap_bytes
+    assert info["ownership_seconds"] > 0.0
+
+
 def test_automatic_layout_is_the_quantile_layout():
     """No cuts given: strips along the longer side at particle-count quantiles (2x2 on four tiles), like bench.py chose them."""
     pos, boundary = dam_break(1.5)
