@@ -10,8 +10,10 @@
 // against (a) the device's sqrtf (the compiler's correctly rounded expansion) and (b) the old fix-up form; a strided sample of the
 // results is checked on the host against sqrt() in double precision rounded once (exact for a 24-bit significand).
 //
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/sqrt_exhaustive tools/sqrt_exhaustive.hip && /tmp/sqrt_exhaustive
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -o /tmp/sqrt_exhaustive tools/sqrt_exhaustive.hip && /tmp/sqrt_exhaustive
 #include <hip/hip_runtime.h>
+
+#include "../yasph2d_amd/csrc/sphx_sqrt.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -39,15 +41,8 @@ __device__ __forceinline__ float sqrt_fixup(float x) {
     s = vp <= 0.0f ? sd : s;
     return vs > 0.0f ? su : s;
 }
-// round 5: the candidate — keep in step with sqrt_dist in sphx_kernels.hip
-__device__ __forceinline__ float sqrt_rsq(float x) {
-    const float y = __builtin_amdgcn_rsqf(x);
-    f32x2 sh = f32x2{x, 0.5f} * f32x2{y, y};                        // {s, h} = {x y, y / 2}
-    const float e = __builtin_fmaf(-sh.y, sh.x, 0.5f);              // 1/2 - h s
-    sh = __builtin_elementwise_fma(sh, f32x2{e, e}, sh);            // s += s e, h += h e (one v_pk_fma_f32)
-    const float d = __builtin_fmaf(-sh.x, sh.x, x);                 // x - s^2, exact to the last bit that matters
-    return __builtin_fmaf(d, sh.y, sh.x);
-}
+// round 5: the candidate — THE function the kernels run (yasph2d_amd/csrc/sphx_sqrt.hpp; round 6: included, not copied)
+__device__ __forceinline__ float sqrt_rsq(float x) { return sphx::sqrt_dist<true>(x); }
 
 struct Result {
     unsigned long long bad_vs_sqrtf, bad_vs_fixup, fixup_vs_sqrtf;

@@ -250,11 +250,11 @@ struct Grid {
     std::vector<uint32_t> h_dir;  // host copy of dir
     bool fine_valid = false;      // `fine` holds the cell ranges of a build made with THIS directory
     uint32_t len() const { return nblk * BLOCK_CELLS; }
+    uint32_t cbits_floor = 1;  // SPHX_CBITS_MIN, read ONCE in sphx_create (a test knob — with 29 a packed word of count_cell has room for
+                               // arrival slots 0..6 only, and ordinary scenes exercise the side array); round 5 read the environment on
+                               // every view(): several getenv calls per step, and not safe against a concurrent setenv
     uint32_t cbits() const {  // bits of a cell index: len() <= 2^cbits - 1, so that no packed word of count_cell equals EMPTY
-        // (SPHX_CBITS_MIN: a test knob — with 29 a word has room for arrival slots 0..6 only, and ordinary scenes exercise the side array)
-        const char* const knob = getenv("SPHX_CBITS_MIN");
-        const uint32_t floor_bits = knob ? (uint32_t)atoi(knob) : 1u;
-        uint32_t b = floor_bits < 1u ? 1u : floor_bits > 31u ? 31u : floor_bits;
+        uint32_t b = cbits_floor < 1u ? 1u : cbits_floor > 31u ? 31u : cbits_floor;
         while (b < 31u && ((1u << b) - 1u) < len()) ++b;
         return b;
     }

@@ -6,6 +6,7 @@
 // CPU evaluation of the reference's formulas (what oracle/ does); the only non-sequential reductions are the two global
 // residual sums (f64 accumulation, fixed tree) and max|v|^2 (exact).
 #include "sphx_internal.hpp"
+#include "sphx_sqrt.hpp"
 
 namespace sphx {
 
@@ -115,21 +116,6 @@ __device__ __forceinline__ uint32_t grid_slot(const GridView& g, uint32_t x, uin
 //    h = 0.02).  v_min_f32 is a 4-cycle instruction.
 // Not FAST: positions were replaced behind the lists' back (sphx_upload with an unchanged particle count: the reference walks its
 // old lists over the new positions too, dfsph.rs:419) or h fails the host's checks: plain sqrtf and the clamp, whatever d2 is.
-template <bool FAST>
-__device__ __forceinline__ float sqrt_dist(float x) {
-    if (!FAST) return sqrtf(x);
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    const float y = __builtin_amdgcn_rsqf(x);
-    // (two plain multiplies — 2-cycle class — into a register pair; as ONE packed multiply of {x, 1/2} by {y, y} the constant has to be
-    // moved into the pair's upper half for every neighbour: 2 + 4 cycles instead of 2 + 2)
-    float s0 = x * y, h0 = 0.5f * y;
-    asm("" : "+v"(s0), "+v"(h0));
-    f32x2_ sh = f32x2_{s0, h0};                             // {s, h} = {x y, y / 2}
-    const float e = __builtin_fmaf(-sh.y, sh.x, 0.5f);      // 1/2 - h s
-    sh = __builtin_elementwise_fma(sh, f32x2_{e, e}, sh);   // s += s e, h += h e
-    const float d = __builtin_fmaf(-sh.x, sh.x, x);         // x - s^2
-    return __builtin_fmaf(d, sh.y, sh.x);
-}
 template <bool FAST>
 __device__ __forceinline__ float clamp_q(float q) { return FAST ? q : fminf(q, 1.0f); }
 // WendlandQuinticC2::evaluate, wendland_quintic_c2.rs:34-39
@@ -461,7 +447,7 @@ __device__ __forceinline__ unsigned long long scan_word(uint32_t epoch, uint32_t
 __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in, uint2* __restrict__ out, uint32_t len,
                                                        unsigned long long* __restrict__ state, uint32_t epoch,
                                                        DevScalars* __restrict__ scal, uint32_t* __restrict__ d_total, Mailbox* __restrict__ mb,
-                                                       uint32_t mb_seq, uint32_t* __restrict__ tile_empty) {
+                                                       uint32_t mb_seq, uint32_t* __restrict__ tile_empty, uint32_t expect_total) {
     const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * SCAN1_TILE;
     const uint32_t was_empty = tile_empty[bid];
@@ -542,6 +528,11 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
     __syncthreads();
     run += excl_s;
     if (bid == gridDim.x - 1 && threadIdx.x == 0 && d_total) *d_total = excl_s + total;  // grand total = particles that got a cell
+    // Outside tile mode EVERY particle must have received a cell: k_rank_gather's fast path takes the cell boundaries from the head
+    // bits of order[0, n) and trusts that this build's scatter rewrote every one of those words (round-5 advisor finding).  A particle
+    // without a cell (a NaN position) breaks that: reported, the host fails the call (expect_total = 0xFFFFFFFF: not checked — tiles,
+    // where the gather clips itself to the total instead).
+    if (bid == gridDim.x - 1 && threadIdx.x == 0 && expect_total != 0xFFFFFFFFu && excl_s + total != expect_total) atomicOr(&scal->flags, DF_OUT_OF_DOMAIN);
     if (mb && bid == gridDim.x - 1) {
         // tile path: the host wants that total (the tile's new local count) as early as possible — published from here instead of
         // from a one-workgroup kernel of its own behind the scan (4.5 us of the stream per re-grid)
