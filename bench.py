@@ -75,7 +75,7 @@ def kernel_source_sha256():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp"):
+    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp", "sphx_sqrt.hpp"):
         try:
             h.update(open(os.path.join(ROOT, "yasph2d_amd", "csrc", f), "rb").read())
         except OSError:
@@ -393,7 +393,7 @@ def main():
 
     fuse_div = os.environ.get("SPHX_FUSE_DIV", "1") != "0"
 
-    def traffic_of(name, n):
+    def traffic_of(name, n, skip=None):
         # HBM traffic of a kernel from the PMC counters: cannot be collected from inside the process; taken from the committed
         # rocprofv3 passes of this same command (profiles/) when the workload matches, else null.
         import glob
@@ -405,6 +405,8 @@ def main():
                 tj = json.load(open(tf))
                 if sha is None or tj.get("kernel_source_sha256") != sha:
                     continue  # counters of another build of the kernels: not this run's traffic
+                if tj.get("skip_steps", 0) != (args.skip_steps if skip is None else skip):
+                    continue  # counters of another window of the run (lists are longer once the fluid is compressed)
                 if abs(tj["workload_particles"] - n) < 0.02 * n and name in tj["bytes_per_launch"]:
                     traffic, src = tj["bytes_per_launch"][name]["total"], tj["source"] + f" [file {os.path.basename(tf)}" + (
                         f", taken at git {tj['git_head']}]" if "git_head" in tj else "]")
@@ -481,7 +483,7 @@ def main():
         if live is not None and live["launches"]:
             ev_ms = ctx.profile_event_overhead()  # what an EMPTY hipEvent bracket measures on this stream, same process
             avg_raw = live["total_ms"] / live["launches"]
-            traffic, traffic_src = traffic_of(dominant, n)
+            traffic, traffic_src = traffic_of(dominant, n, skip_steps)
             # per-kernel table: a short extra pass with every launch timed, outside the timed region
             ctx.profile_reset()
             ctx.profile_enable(True)
@@ -521,7 +523,7 @@ def main():
             # `traffic`), launch duration and launches per step live from this run's every-launch pass (event-inflated, see note).
             ledger = {}
             for kname, v in sorted(prof.items()):
-                kb, _ = traffic_of(kname, n)
+                kb, _ = traffic_of(kname, n, skip_steps)
                 if not v["launches"]:
                     continue
                 us = max(v["total_ms"] / v["launches"] - infl, 1e-6) * 1e3

@@ -2,7 +2,7 @@
 """profiles/<prefix>_traffic_<tag>.json from the FETCH_SIZE / WRITE_SIZE tables of tools/summarize_profile.py (separate rocprofv3
 passes of `python3 bench.py ...`).  bench.py reads it for roofline.traffic (the counters cannot be read from inside the process).
 
-usage: make_traffic_json.py fetch.txt write.txt particles out.json "source text" [git head]
+usage: make_traffic_json.py fetch.txt write.txt particles out.json "source text" [git head] [skip_steps]
 """
 import json
 import sys
@@ -28,7 +28,7 @@ def kernel_source_sha256():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp"):
+    for f in ("sphx_kernels.hip", "sphx_launch.inc", "sphx_internal.hpp", "sphx_sqrt.hpp"):
         h.update(open(os.path.join(root, "yasph2d_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -57,6 +57,8 @@ if __name__ == "__main__":
     doc = {"workload_particles": int(sys.argv[3]), "source": sys.argv[5], "bytes_per_launch": res}
     if len(sys.argv) > 6 and sys.argv[6]:
         doc["git_head"] = sys.argv[6]  # the build the counters were taken from (bench.py quotes it next to roofline.traffic)
+    if len(sys.argv) > 7 and sys.argv[7]:
+        doc["skip_steps"] = int(sys.argv[7])  # the window the counters belong to (bench.py --skip-steps); absent: from t = 0
     doc["kernel_source_sha256"] = kernel_source_sha256()  # bench.py only quotes a record taken from the kernels it runs
     json.dump(doc, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(res, indent=1)[:400])

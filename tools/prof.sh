@@ -3,6 +3,7 @@
 #   tools/prof.sh stats  OUT VARIANT...   kernel durations (rocprofv3 --kernel-trace --stats), one column per variant, same box
 #   tools/prof.sh tail   OUT N VARIANT... the same over the LAST N dispatches only (the timed window of a --skip-steps run)
 #   tools/prof.sh stamps OUT VARIANT...   in-kernel phase stamps of variants built with -DSPHX_STAMPS
+#   tools/prof.sh bench  OUT VARIANT...   un-profiled bench.py runs, alternating (PROF_REPEAT rounds): us per step
 #   tools/prof.sh pmc    OUT NAME COUNTER...  one counter pass (own run, --kernel-trace only, as MI355X_MICROARCH.md prescribes)
 #   tools/prof.sh env    OUT "A=1 B=2" ...    stats columns for environment settings of the PRODUCT library (name=ENVSTRING)
 # VARIANT = base (the product library) or NAME of yasph2d_amd/variants/libsphx_NAME.so (tools/ab_build.sh NAME -D...).
@@ -71,6 +72,13 @@ stamps)
     lib $v
     timeout 600 $B --steps 20 > $out/bench_$v.json 2> $out/bench_$v.err
     echo "== $v"; grep SPHX_STAMPS $out/bench_$v.err | tail -4
+  done ;;
+bench)   # un-profiled step time, variants alternating, PROF_REPEAT rounds (default 3): what the driver's clock sees
+  for r in $(seq 1 ${PROF_REPEAT:-3}); do
+    for vv in "$@"; do
+      if [[ "$vv" == *=* ]]; then v=${vv%%=*}; e=${vv#*=}; lib base; else v=$vv; e=""; lib $vv; fi
+      env $e $B --steps ${PROF_STEPS:-100} --warmup 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step']*1000,1), 'us/step', round(d['value']/1e9,3), 'G/s')" | tee -a $out/bench.txt
+    done
   done ;;
 pmc)
   name=$1; shift

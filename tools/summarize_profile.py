@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small per-round summaries committed under profiles/.
 
-usage: summarize_profile.py <kernel_stats.csv | counter_collection.csv> [--steps K]
+usage: summarize_profile.py <kernel_stats.csv | counter_collection.csv> [--last N]   (--last: counter files, the last N dispatches only)
   kernel_stats        -> per-kernel calls / avg us / % table
   counter_collection  -> per-kernel mean counter value; FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3 and
                          FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950.
@@ -18,8 +18,12 @@ def short(name):
     return m.group(2) if m else name[:40]
 
 
-def main(path):
+def main(path, last=0):
     rows = list(csv.DictReader(open(path)))
+    if last and "Dispatch_Id" in rows[0]:  # the last `last` dispatches only (the timed window of a --skip-steps run)
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-last:]
+        keep = set(ids)
+        rows = [r for r in rows if int(r["Dispatch_Id"]) in keep]
     if "TotalDurationNs" in rows[0]:
         print(f"{'kernel':48s} {'calls':>7s} {'avg_us':>9s} {'total_ms':>9s} {'pct':>6s}")
         for r in rows:
@@ -40,4 +44,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0)
