@@ -395,13 +395,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t* __restrict__ in, u
             v[4 * k + 1] = q.y;
             v[4 * k + 2] = q.z;
             v[4 * k + 3] = q.w;
+#ifdef SPHX_SLOT_AT_COUNT
             p4[k] = make_uint4(0, 0, 0, 0);
+#endif
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             v[k] = (t0 + k < len) ? in[t0 + k] : 0;
+#ifdef SPHX_SLOT_AT_COUNT
             if (t0 + k < len) in[t0 + k] = 0;
+#endif
         }
     }
 #pragma unroll
@@ -466,12 +470,16 @@ __global__ __launch_bounds__(256) void k_scan_onepass(uint32_t* __restrict__ in,
             uint4* const p4 = reinterpret_cast<uint4*>(in + t);
             const uint4 q = *p4;
             v[k][0] = q.x, v[k][1] = q.y, v[k][2] = q.z, v[k][3] = q.w;
+#ifdef SPHX_SLOT_AT_COUNT
             if ((q.x | q.y | q.z | q.w) != 0u) *p4 = make_uint4(0, 0, 0, 0);  // the histogram is re-zeroed where it was not zero
+#endif  // (round 6: k_scatter counts it down to zero again)
         } else {
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
                 v[k][c] = (t + c < len) ? in[t + c] : 0u;
+#ifdef SPHX_SLOT_AT_COUNT
                 if (t + c < len && v[k][c] != 0u) in[t + c] = 0u;
+#endif
             }
         }
     }
@@ -620,6 +628,7 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
     const uint32_t start = 63u - (uint32_t)__clzll(mask & (~0ull >> (63u - lane)));
     const unsigned long long rest = (lane == 63) ? 0ull : (mask >> (lane + 1));
     const uint32_t end = rest ? lane + (uint32_t)__ffsll((long long)rest) : 64u;
+#ifdef SPHX_SLOT_AT_COUNT  // (rounds 1-5: the arrival slot taken HERE, with the atomic's returned value, and packed into the word)
     uint32_t base = 0;
     if (head && idx != EMPTY) base = atomicAdd(&hist[idx], end - lane);
     base = __shfl(base, start, 64);
@@ -628,6 +637,18 @@ __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, b
         cidx[i] = (idx != EMPTY) ? idx | (min(sl, sl_max) << g.cbits) : EMPTY;
         if (idx != EMPTY && sl >= sl_max) slot[i] = sl;
     }
+#else
+    // Round 6: the count only COUNTS — a no-return atomic, nothing to wait for.  The returning form ended every workgroup of the last
+    // density correction with a memory round trip (the slot had to come back before the packed word could be stored): 62 500
+    // workgroups in 30 generations of the chip, ~1.5 us each — most of the 56 us the fused count cost that kernel at 16 M
+    // (profiles/r06_experiments/fused_count.txt).  The slot inside the cell is taken where it is used, by k_scatter: it counts the
+    // histogram DOWN again (the returned value is the slot; four particles per lane in flight), which also leaves the histogram
+    // all-zero for the next count — the scan no longer clears it.
+    (void)slot;
+    (void)start;
+    if (head && idx != EMPTY) atomicAdd(&hist[idx], end - lane);
+    if (live) cidx[i] = idx;
+#endif
 }
 // first: the pass covers particles [first, n) (the tile path counts the particles it kept while the halo exchange is in flight and
 // the received ones afterwards)
@@ -658,7 +679,8 @@ constexpr uint32_t ORDER_HEAD = 0x80000000u, ORDER_INDEX = 0x7FFFFFFFu;  // (con
 // wavefronts keeps ~2 MB in flight and ran at 3.3 TB/s whatever it read; profiles/r05_experiments/regrid.txt.)
 constexpr uint32_t SCATTER_PER_LANE = 4;
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
-                                                  const uint2* __restrict__ fine, uint32_t* __restrict__ order, uint32_t cbits) {
+                                                  const uint2* __restrict__ fine, uint32_t* __restrict__ order, uint32_t cbits,
+                                                  uint32_t* __restrict__ hist) {
     // (lane t of a workgroup takes the particles b0 + t, b0 + 256 + t, ...: every load and every store of a wavefront is one run of
     // consecutive words — particles arrive nearly sorted, so consecutive particles go to consecutive slots)
     const uint32_t b0 = xcd_bid() * (256u * SCATTER_PER_LANE) + threadIdx.x;
@@ -669,6 +691,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
     uint32_t first[SCATTER_PER_LANE];
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) first[u] = fine[w[u] == EMPTY ? 0u : w[u] & ((1u << cbits) - 1u)].x;  // four gathers in flight
+#ifdef SPHX_SLOT_AT_COUNT
+    (void)hist;
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) {
         if (w[u] == EMPTY) continue;
@@ -678,6 +702,38 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
         const uint32_t p = first[u] + sl;
         if (p < n) order[p] = i | (sl == 0u ? ORDER_HEAD : 0u);
     }
+#else
+    // The slot inside the cell (count_cell): the histogram holds each cell's population; a run of lanes with the same cell takes it
+    // down by the run's length with ONE returning atomic and shares out the slots old - 1, old - 2, ... — every particle of the cell
+    // gets one of 0 .. population - 1, whoever comes first, and the histogram is back at zero when the last one has been.  The four
+    // atomics of a lane are in flight together with its four table look-ups.
+    (void)slot;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t old[SCATTER_PER_LANE], pos_in_run[SCATTER_PER_LANE];
+#pragma unroll
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) {
+        const uint32_t idx = w[u];
+        const uint32_t prev = dpp_mov<0x138>(idx, idx);  // wave_shr:1 (lane 0: its own; unused)
+        const bool head = (lane == 0) || (idx != prev);
+        const unsigned long long mask = __ballot(head);
+        const uint32_t start = 63u - (uint32_t)__clzll(mask & (~0ull >> (63u - lane)));
+        const unsigned long long rest = (lane == 63) ? 0ull : (mask >> (lane + 1));
+        const uint32_t end = rest ? lane + (uint32_t)__ffsll((long long)rest) : 64u;
+        uint32_t o = 0;
+        if (head && idx != EMPTY) o = atomicSub(&hist[idx], end - lane);
+        old[u] = o;
+        pos_in_run[u] = (start << 8) | (lane - start);  // (the hand-out below needs the head lane's value: shuffled once all four are back)
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) {
+        const uint32_t o = (uint32_t)__shfl((int)old[u], (int)(pos_in_run[u] >> 8), 64);
+        if (w[u] == EMPTY) continue;
+        const uint32_t i = b0 + u * 256u;
+        const uint32_t sl = o - 1u - (pos_in_run[u] & 0xFFu);
+        const uint32_t p = first[u] + sl;
+        if (p < n) order[p] = i | (sl == 0u ? ORDER_HEAD : 0u);
+    }
+#endif
 }
 
 struct GatherArgs {
