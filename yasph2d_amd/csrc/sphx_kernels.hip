@@ -677,7 +677,10 @@ __global__ __launch_bounds__(256) void k_key_count(PVr PV, const float2* __restr
 constexpr uint32_t ORDER_HEAD = 0x80000000u, ORDER_INDEX = 0x7FFFFFFFu;  // (contexts hold < 2^28 slots)
 // (Round 5: FOUR particles per lane.  With one, the kernel was two dependent loads and a store per lane — a chip full of such
 // wavefronts keeps ~2 MB in flight and ran at 3.3 TB/s whatever it read; profiles/r05_experiments/regrid.txt.)
-constexpr uint32_t SCATTER_PER_LANE = 4;
+#ifndef SPHX_SCATTER_PER_LANE
+#define SPHX_SCATTER_PER_LANE 4
+#endif
+constexpr uint32_t SCATTER_PER_LANE = SPHX_SCATTER_PER_LANE;
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ slot, uint32_t n,
                                                   const uint2* __restrict__ fine, uint32_t* __restrict__ order, uint32_t cbits,
                                                   uint32_t* __restrict__ hist) {
