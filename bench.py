@@ -543,7 +543,7 @@ def main():
             vrec = valu_of(dominant, n) if dominant.startswith("neighbor_build") else None
             if vrec and vrec.get("active_inst_valu"):
                 # The neighbour build is far from its HBM roofline and NOT simply bound by vector issue either (DESIGN.md section 4,
-                # profiles/r05_experiments/build_phase_stamps.txt: +9 % / +18 % vector instructions cost +2.8 % / +3.3 % time): it sits at the
+                # profiles/r05_experiments/build_phase_stamps.txt, profiles/r06_experiments/far_prefetch.txt): it sits at the
                 # knee between its vector time and the chain of round trips a wavefront waits for (rounds 3-4 said "valu" in `bound`, round 5
                 # "hbm"; since round 6 it says "latency+issue" while frac < 0.5).  The issue-slot occupancy is stated beside it — only when the
                 # committed SQ counters were taken from THESE kernels (kernel_source_sha256).

@@ -1,6 +1,6 @@
 """Parity tests proper: the HIP path (through the C ABI, include/sphx.h) against the CPU oracle on the same inputs.
 
-Bar (see DESIGN.md §6): cell arrays, sorted order, neighbour counts and neighbour indices bit-exact; fp32 positions,
+Bar (see DESIGN.md §5): cell arrays, sorted order, neighbour counts and neighbour indices bit-exact; fp32 positions,
 velocities, densities, alpha, kappa bit-identical too (the kernels keep the reference's operation order, un-fused, with
 correctly rounded div/sqrt), so the tolerance written here is ZERO ulp.  The only values that may differ are the two
 residual averages when an f64 partial-sum rounding lands on an f32 tie (never observed; reported, compared at 1 ulp).
