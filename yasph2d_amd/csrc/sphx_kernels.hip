@@ -588,9 +588,8 @@ struct CountArgs {
 // position update x += v* dt (dfsph.rs:499-510) in front.  Particles arrive almost sorted (they were in cell order one step
 // ago), so equal cells sit in adjacent lanes: each run of equal cells inside a wavefront does ONE atomic for the whole run.
 // The value returned by the atomic is an arbitrary arrival slot inside the cell; k_rank_gather restores the stable order.
-// cidx[i] = the particle's index into the fine table and that arrival slot in ONE word (GridView::cbits; round 5: a second array of
-// slots was 4 bytes per particle written here and 4 read by the scatter) — the slot[] array only receives the slots that do not fit
-// the word's upper bits (a cell with hundreds of particles: a collapse, or strays parked in the table's first cell).
+// cidx[i] = the particle's index into the fine table (round 6; rounds 1-5 — SPHX_SLOT_AT_COUNT — also took the arrival slot here, from
+// the atomic's returned value, and packed it into the word's upper bits, GridView::cbits, with a side array for slots that did not fit).
 // Called by ALL lanes of a wavefront (live = this lane holds particle i at position p).
 __device__ __forceinline__ void count_cell(const Consts& K, const GridView& g, bool live, uint32_t i, float2 p, uint32_t* __restrict__ hist,
                                            uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring, DevScalars* __restrict__ scal,
@@ -1288,7 +1287,7 @@ __device__ __forceinline__ void ranges9n(const NbGrid& g, const uint32_t (&slot)
 // cell ranges are requested before the one barrier of the kernel; the candidate scan handles four candidates per trip; the list
 // format is decided per WAVEFRONT (no second barrier), the statistics are added per wavefront (no third one).  Since round 3 it is
 // bound by the number of VECTOR INSTRUCTIONS a wavefront issues (a wave64 instruction occupies its SIMD for four cycles): round 4
-// took 1 452 -> see DESIGN.md section 4 for where they went.
+// took 1 452 -> 1 164, round 5 -> 1 155; DESIGN.md section 4, "What bounds the kernels" (history: profiles/history/DESIGN_r05.md).
 #ifndef NB_BOUNDS
 #define NB_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
