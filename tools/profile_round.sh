@@ -1,13 +1,14 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the rocprofv3 passes and bench lines whose summaries are committed under profiles/ as <PREFIX>_*.
-#   tools/profile_round.sh PREFIX OUTDIR [prof]        e.g. tools/profile_round.sh r06 gpurun_out/r06_final
+#   tools/profile_round.sh PREFIX OUTDIR [prof|bench]   e.g. tools/profile_round.sh r06 gpurun_out/r06_final prof; copy the records; ... bench
 P=$1
 out=$GRAFT_REPO_ROOT/$2
 mkdir -p $out
+MODE=$3   # prof: counter / trace passes only; bench: bench lines only (run it AFTER the passes' JSON records have been copied to profiles/: bench.py quotes them); empty: both
 cd /tmp && export TMPDIR=/tmp
 # (--prewarm-ms 0: the profile holds the measured context's launches only, not the scratch context's clock warm-up)
 B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-also --prewarm-ms 0"
-run() { name=$1; shift; timeout 900 rocprofv3 "$@" --output-format csv -d $out/$name -- $B $ARGS > $out/$name.log 2>&1; echo "$name rc=$?"; }
+run() { [ "$MODE" = bench ] && return; name=$1; shift; timeout 900 rocprofv3 "$@" --output-format csv -d $out/$name -- $B $ARGS > $out/$name.log 2>&1; echo "$name rc=$?"; }
 SQ="--pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD"
 ARGS="--steps 100 --warmup 5 --particles 1000000"
 run stats_1M --kernel-trace --stats
@@ -32,6 +33,7 @@ run fetch_16M_window2500 --pmc FETCH_SIZE --kernel-trace
 run write_16M_window2500 --pmc WRITE_SIZE --kernel-trace
 run sq_16M_iterating_window2500 $SQ --kernel-trace
 cd $GRAFT_REPO_ROOT
+if [ "$MODE" != bench ]; then
 S=tools/summarize_profile.py
 for n in stats_1M stats_16M stats_1M_iterating_fixed32 stats_1M_iterating_window3750 stats_16M_iterating_window2500; do
   f=$(find $out/$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 $S $f > $out/$n.txt
@@ -50,7 +52,8 @@ python3 tools/make_traffic_json.py $out/fetch_16M_window2500.txt $out/write_16M_
 VS="rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... --kernel-trace (python3 bench.py"
 python3 tools/make_valu_json.py $out/sq_1M.txt 999698 $out/valu_1M.json "$VS --particles 1000000), profiles/${P}_sq_1M.txt" "$HEAD" > /dev/null
 python3 tools/make_valu_json.py $out/sq_16M.txt 15995168 $out/valu_16M.json "$VS, the default 16 M workload), profiles/${P}_sq_16M.txt" "$HEAD" > /dev/null
-if [ "$3" = prof ]; then find $out -name "*.csv" -delete; find $out -type d -empty -delete; exit 0; fi
+fi
+if [ "$MODE" = prof ]; then find $out -name "*.csv" -delete; find $out -type d -empty -delete; exit 0; fi
 # bench lines (with roofline + cpu_baseline) of the same build
 b() { name=$1; shift; timeout 900 python3 bench.py "$@" > $out/bench_$name.json 2> $out/bench_$name.err; echo "bench $name rc=$?"; }
 b default --steps 20 --warmup 5

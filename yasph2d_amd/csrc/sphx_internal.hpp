@@ -89,6 +89,7 @@ struct Consts {
     // the min(q, 1) of WendlandQuinticC2::evaluate / gradient (wendland_quintic_c2.rs:35,43) is the identity and the sqrt's argument
     // is far from the ends of the exponent range
     uint32_t q_noclamp;
+    uint32_t rev;  // this launch sweeps the particle blocks from the top down (xcd_bid; alternates from launch to launch, sphx_ctx::alternate_sweep)
 };
 
 // wave-sliced neighbour lists (one 16 KiB slice per 64 particles); counts[i] = count_dynamic | count_total << 7 = NeighborRange
@@ -365,6 +366,7 @@ struct sphx_ctx {
     uint32_t tile_class_n = 0, tile_class_dt_bits = 0;
     bool tile_fix_owner = false;    // the re-grid's gather clears the owner bit of kept particles that left the own rectangle
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
+    int alternate_sweep = 1;       // SPHX_ALTERNATE_SWEEP=0: every launch sweeps the particle blocks bottom-up (rounds 1-5)
     int fuse_warm = 1;             // SPHX_FUSE_WARM=0: the divergence warm start is never folded into the neighbour build (A/B)
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it
     bool div_warm_fused = false;   // the latest neighbour build applied the divergence loop's warm start
