@@ -207,3 +207,18 @@ def test_sort9_monotone_network_sorts_every_box_with_ascending_rows_and_columns(
         for cy in range(1, 63, 7):
             slots = [(spread(cy + dy) << 1) | spread(cx + dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
             assert run(slots) == sorted(slots)
+
+
+def test_block_mapping_is_a_permutation_in_both_sweep_directions():
+    """xcd_bid(rev) (sphx_kernels.hip): workgroup b of a grid of G (a multiple of 8) takes particle block (b mod 8) * (G / 8) + q with
+    q = b / 8 bottom-up or G / 8 - 1 - b / 8 top-down (round 6: consecutive launches alternate).  Either way every block is taken
+    exactly once, XCD x (= b mod 8) keeps the x-th eighth, and the top-down order is the bottom-up order of each eighth reversed."""
+    for g in (8, 16, 64, 3912, 62504):
+        per = g // 8
+        fwd = [(b & 7) * per + (b >> 3) for b in range(g)]
+        rev = [(b & 7) * per + (per - 1 - (b >> 3)) for b in range(g)]
+        assert sorted(fwd) == list(range(g)) and sorted(rev) == list(range(g))
+        for x in range(8):
+            f = [blk for b, blk in enumerate(fwd) if b & 7 == x]
+            r = [blk for b, blk in enumerate(rev) if b & 7 == x]
+            assert f == list(range(x * per, (x + 1) * per)) and r == f[::-1]
