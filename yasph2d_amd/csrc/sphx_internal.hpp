@@ -89,6 +89,7 @@ struct Consts {
     // the min(q, 1) of WendlandQuinticC2::evaluate / gradient (wendland_quintic_c2.rs:35,43) is the identity and the sqrt's argument
     // is far from the ends of the exponent range
     uint32_t q_noclamp;
+    uint32_t nt_cold;  // outputs that nobody reads before the next step (density, alpha, warm-start sums, ids) are stored with the nontemporal hint
     uint32_t rev;  // this launch sweeps the particle blocks from the top down (xcd_bid; alternates from launch to launch, sphx_ctx::alternate_sweep)
 };
 
@@ -385,6 +386,7 @@ struct sphx_ctx {
     bool in_wcsph = false;
     int lazy_table = 1;  // SPHX_LAZY_TABLE=0 (A/B runs): every walk fetches all 128 table lines of its wavefront
     int stream_lists = -1;  // SPHX_STREAM_LISTS=0/1 (A/B runs); -1: by size
+    int nt_cold_stores = -1;  // SPHX_NT_COLD_STORES=0/1 (A/B runs); -1: by size (on from 4 M particles, Consts::nt_cold)
     sphx::NbView nbv() const {
         return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table, stream_lists < 0 ? (N >= 4000000u ? 1u : 0u) : (uint32_t)stream_lists};
     }

@@ -188,6 +188,16 @@ __device__ __forceinline__ T gat(const T* __restrict__ base, uint32_t idx) {
     return *(const T*)((const char*)base + (uint32_t)(idx * (uint32_t)sizeof(T)));
 }
 
+// A 4-byte store of a COLD output (Consts::nt_cold): with the nontemporal hint when the context says so.  Inline assembly: as
+// `if (nt) __builtin_nontemporal_store(..) else *p = ..` the optimiser merges the two arms into ONE plain store (checked in the ISA).
+__device__ __forceinline__ void store_cold(float* p, float v, uint32_t nt) {
+    if (nt)
+        asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else
+        *p = v;
+}
+__device__ __forceinline__ void store_cold(uint32_t* p, uint32_t v, uint32_t nt) { store_cold((float*)p, __uint_as_float(v), nt); }
+
 // Positions and velocities live in two float2 arrays ([N|B], boundary tail: v = 0): the kernels that only change velocities (the
 // prediction, the four corrections) then read and write 8 bytes of their particle's record instead of 16 — writes are line-granular,
 // a half-written 16-byte record costs its full line.  A kernel that needs both halves of a record loads them as a pair.
@@ -696,7 +706,11 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
     if (b0 - threadIdx.x >= n) return;
     uint32_t w[SCATTER_PER_LANE];
 #pragma unroll
+#ifdef SPHX_NT_DEAD_LOADS
+    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = b0 + u * 256u < n ? __builtin_nontemporal_load(&cidx[b0 + u * 256u]) : EMPTY;
+#else
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = b0 + u * 256u < n ? cidx[b0 + u * 256u] : EMPTY;
+#endif
     uint32_t first[SCATTER_PER_LANE];
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) first[u] = fine[w[u] == EMPTY ? 0u : w[u] & ((1u << cbits) - 1u)].x;  // four gathers in flight
@@ -771,6 +785,7 @@ struct GatherArgs {
     // their previous index — an order every tiling of the domain arrives at (a tile appends what it receives behind what it holds,
     // so "previous index" means something else on every tile)
     uint32_t rank_by_id;
+    uint32_t nt_cold;  // Consts::nt_cold
 };
 #ifndef SPHX_GATHER_PER_LANE
 #define SPHX_GATHER_PER_LANE 1
@@ -822,10 +837,21 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         const uint32_t i = own[u] & ORDER_INDEX;
         ok[u] = b0 + u * 256u + threadIdx.x < n && i < n_in;
         const uint32_t ic = ok[u] ? i : 0u;
+#ifdef SPHX_NT_DEAD_LOADS  // (experiment: the unsorted records are dead once they have been moved)
+        {
+            const unsigned long long qq = __builtin_nontemporal_load((const unsigned long long*)&a.pos_in[ic]);
+            q[u] = make_float2(__uint_as_float((uint32_t)qq), __uint_as_float((uint32_t)(qq >> 32)));
+            const unsigned long long vv = a.vel_in ? __builtin_nontemporal_load((const unsigned long long*)&a.vel_in[ic]) : 0ull;
+            v[u] = make_float2(__uint_as_float((uint32_t)vv), __uint_as_float((uint32_t)(vv >> 32)));
+        }
+        r1[u] = a.r_in ? a.r_in[ic] : 0.0f, r2[u] = a.r2_in ? a.r2_in[ic] : 0.0f, r3[u] = a.r3_in ? a.r3_in[ic] : 0.0f;
+        id[u] = a.u_in ? __builtin_nontemporal_load(&a.u_in[ic]) : 0u;
+#else
         q[u] = a.pos_in[ic];
         v[u] = a.vel_in ? a.vel_in[ic] : make_float2(0.0f, 0.0f);
         r1[u] = a.r_in ? a.r_in[ic] : 0.0f, r2[u] = a.r2_in ? a.r2_in[ic] : 0.0f, r3[u] = a.r3_in ? a.r3_in[ic] : 0.0f;
         id[u] = a.u_in ? a.u_in[ic] : 0u;
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -908,7 +934,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
                 const uint32_t cx = sat_u16((qd.x - a.gmin_x) * a.cell_inv), cy = sat_u16((qd.y - a.gmin_y) * a.cell_inv);  // cell_of()
                 if (!rect_has(a.own, cx, cy, 0u)) idd &= 0x7FFFFFFFu;
             }
-            a.u_out[dst] = idd;
+            store_cold(&a.u_out[dst], idd, a.nt_cold);  // (ids are read again by the next gather: a step away)
             if (a.count_owned) {
                 const unsigned long long m = __ballot((idd >> 31) != 0);
                 if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
@@ -1556,9 +1582,12 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     if (FUSE && live) {
         const float gsx = gs2.x, gsy = gs2.y, wsx = ws.x, wsy = ws.y;
         const uint32_t i4 = i * 4u;  // (scalar base + 32-bit lane offset: contexts hold < 2^28 slots)
-        *(float*)((char*)density + i4) = fmaxf(rho, K.rho0);            // fluidparticleworld.rs:229
         const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
-        *(float*)((char*)alpha + i4) = alpha_i;
+        // (Consts::nt_cold — round 6, contexts of >= 4 M particles: outputs nobody reads before the NEXT STEP are stored with the
+        // nontemporal hint and leave the Infinity Cache to the lines the next kernel re-reads (alternating sweeps, xcd_bid): -1.1 % per
+        // step at 16 M; at 1 M, where the whole step's arrays stay cached, the hint costs 3 %: profiles/r06_experiments/cold_stores.txt)
+        store_cold((float*)((char*)density + i4), fmaxf(rho, K.rho0), K.nt_cold);  // fluidparticleworld.rs:229
+        store_cold((float*)((char*)alpha + i4), alpha_i, K.nt_cold);
         if (DIV) {
             const float e = ct < 9u ? 0.0f : fmaxf(delta * K.mass, 0.0f);  // dfsph.rs:261, :277-278
             *(float*)((char*)dv.kbuf + i4) = e * alpha_i;  // (the warm-start stiffness is not zeroed here: the loop's first correction starts it from zero)
@@ -2609,8 +2638,13 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     // this particle's scalars are requested together with everything else (one round trip, not two)
+#ifdef SPHX_NT_DEAD_LOADS
+    const float rho_i = (!DIVERGENCE && i < n) ? __builtin_nontemporal_load(&density[i]) : 0.0f;
+    const float alpha_i = i < n ? __builtin_nontemporal_load(&alpha[i]) : 0.0f;
+#else
     const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
     const float alpha_i = i < n ? alpha[i] : 0.0f;
+#endif
     struct PredRec {
         float4 pv;
         float2 a;
@@ -2887,7 +2921,9 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
             o.y = pvi.w - dy * K.mass;
         }
         vel[i] = o;
-        if (!WARM) warm[i] = warm_i + ki;  // dfsph.rs:142 / :296
+        if (!WARM) {  // dfsph.rs:142 / :296 (read again by the next step's loop: Consts::nt_cold)
+            store_cold(&warm[i], warm_i + ki, K.nt_cold);
+        }
         pnew = make_float2(pvi.x + o.x * dt, pvi.y + o.y * dt);  // dfsph.rs:499-510, the operations of k_key_count<true>
     }
     if (!WARM && INV_DT)
