@@ -706,11 +706,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
     if (b0 - threadIdx.x >= n) return;
     uint32_t w[SCATTER_PER_LANE];
 #pragma unroll
-#ifdef SPHX_NT_DEAD_LOADS
-    for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = b0 + u * 256u < n ? __builtin_nontemporal_load(&cidx[b0 + u * 256u]) : EMPTY;
-#else
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) w[u] = b0 + u * 256u < n ? cidx[b0 + u * 256u] : EMPTY;
-#endif
     uint32_t first[SCATTER_PER_LANE];
 #pragma unroll
     for (uint32_t u = 0; u < SCATTER_PER_LANE; ++u) first[u] = fine[w[u] == EMPTY ? 0u : w[u] & ((1u << cbits) - 1u)].x;  // four gathers in flight
@@ -837,21 +833,10 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
         const uint32_t i = own[u] & ORDER_INDEX;
         ok[u] = b0 + u * 256u + threadIdx.x < n && i < n_in;
         const uint32_t ic = ok[u] ? i : 0u;
-#ifdef SPHX_NT_DEAD_LOADS  // (experiment: the unsorted records are dead once they have been moved)
-        {
-            const unsigned long long qq = __builtin_nontemporal_load((const unsigned long long*)&a.pos_in[ic]);
-            q[u] = make_float2(__uint_as_float((uint32_t)qq), __uint_as_float((uint32_t)(qq >> 32)));
-            const unsigned long long vv = a.vel_in ? __builtin_nontemporal_load((const unsigned long long*)&a.vel_in[ic]) : 0ull;
-            v[u] = make_float2(__uint_as_float((uint32_t)vv), __uint_as_float((uint32_t)(vv >> 32)));
-        }
-        r1[u] = a.r_in ? a.r_in[ic] : 0.0f, r2[u] = a.r2_in ? a.r2_in[ic] : 0.0f, r3[u] = a.r3_in ? a.r3_in[ic] : 0.0f;
-        id[u] = a.u_in ? __builtin_nontemporal_load(&a.u_in[ic]) : 0u;
-#else
         q[u] = a.pos_in[ic];
         v[u] = a.vel_in ? a.vel_in[ic] : make_float2(0.0f, 0.0f);
         r1[u] = a.r_in ? a.r_in[ic] : 0.0f, r2[u] = a.r2_in ? a.r2_in[ic] : 0.0f, r3[u] = a.r3_in ? a.r3_in[ic] : 0.0f;
         id[u] = a.u_in ? a.u_in[ic] : 0u;
-#endif
     }
     __syncthreads();
 #pragma unroll
@@ -2638,13 +2623,8 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     // this particle's scalars are requested together with everything else (one round trip, not two)
-#ifdef SPHX_NT_DEAD_LOADS
-    const float rho_i = (!DIVERGENCE && i < n) ? __builtin_nontemporal_load(&density[i]) : 0.0f;
-    const float alpha_i = i < n ? __builtin_nontemporal_load(&alpha[i]) : 0.0f;
-#else
     const float rho_i = (!DIVERGENCE && i < n) ? density[i] : 0.0f;
     const float alpha_i = i < n ? alpha[i] : 0.0f;
-#endif
     struct PredRec {
         float4 pv;
         float2 a;
