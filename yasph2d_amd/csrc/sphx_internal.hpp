@@ -386,7 +386,7 @@ struct sphx_ctx {
     bool in_wcsph = false;
     int lazy_table = 1;  // SPHX_LAZY_TABLE=0 (A/B runs): every walk fetches all 128 table lines of its wavefront
     int stream_lists = -1;  // SPHX_STREAM_LISTS=0/1 (A/B runs); -1: by size
-    int nt_cold_stores = -1;  // SPHX_NT_COLD_STORES=0/1 (A/B runs); -1: by size (on from 4 M particles, Consts::nt_cold)
+    int nt_cold_stores = -1;  // SPHX_NT_COLD_STORES=0/1 (A/B runs); -1: by size (on from 6 M particles, Consts::nt_cold)
     sphx::NbView nbv() const {
         return sphx::NbView{nb_list, nb_counts, nb_wave, nb_remote, (uint32_t)lazy_table, stream_lists < 0 ? (N >= 4000000u ? 1u : 0u) : (uint32_t)stream_lists};
     }

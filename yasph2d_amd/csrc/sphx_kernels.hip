@@ -1568,7 +1568,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
         const float gsx = gs2.x, gsy = gs2.y, wsx = ws.x, wsy = ws.y;
         const uint32_t i4 = i * 4u;  // (scalar base + 32-bit lane offset: contexts hold < 2^28 slots)
         const float alpha_i = 1.0f / fmaxf((gsx * gsx + gsy * gsy) + gss, 1e-6f);  // dfsph.rs:94
-        // (Consts::nt_cold — round 6, contexts of >= 4 M particles: outputs nobody reads before the NEXT STEP are stored with the
+        // (Consts::nt_cold — round 6, contexts of >= 6 M particles: outputs nobody reads before the NEXT STEP are stored with the
         // nontemporal hint and leave the Infinity Cache to the lines the next kernel re-reads (alternating sweeps, xcd_bid): -1.1 % per
         // step at 16 M; at 1 M, where the whole step's arrays stay cached, the hint costs 3 %: profiles/r06_experiments/cold_stores.txt)
         store_cold((float*)((char*)density + i4), fmaxf(rho, K.rho0), K.nt_cold);  // fluidparticleworld.rs:229
