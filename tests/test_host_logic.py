@@ -210,15 +210,32 @@ def test_sort9_monotone_network_sorts_every_box_with_ascending_rows_and_columns(
 
 
 def test_block_mapping_is_a_permutation_in_both_sweep_directions():
-    """xcd_bid(rev) (sphx_kernels.hip): workgroup b of a grid of G (a multiple of 8) takes particle block (b mod 8) * (G / 8) + q with
-    q = b / 8 bottom-up or G / 8 - 1 - b / 8 top-down (round 6: consecutive launches alternate).  Either way every block is taken
-    exactly once, XCD x (= b mod 8) keeps the x-th eighth, and the top-down order is the bottom-up order of each eighth reversed."""
-    for g in (8, 16, 64, 3912, 62504):
-        per = g // 8
-        fwd = [(b & 7) * per + (b >> 3) for b in range(g)]
-        rev = [(b & 7) * per + (per - 1 - (b >> 3)) for b in range(g)]
-        assert sorted(fwd) == list(range(g)) and sorted(rev) == list(range(g))
-        for x in range(8):
-            f = [blk for b, blk in enumerate(fwd) if b & 7 == x]
-            r = [blk for b, blk in enumerate(rev) if b & 7 == x]
-            assert f == list(range(x * per, (x + 1) * per)) and r == f[::-1]
+    """xcd_bid(rev, shift) (sphx_kernels.hip): workgroup b of a grid of G (a multiple of 8) belongs to XCD x = b mod 8 and is that
+    XCD's q-th workgroup, q = b / 8 bottom-up or G / 8 - 1 - b / 8 top-down (round 6: consecutive launches alternate).  XCD x takes
+    every eighth chunk of 2^shift consecutive particle blocks (and an eighth of the short last group); shift 0: one contiguous eighth
+    (rounds 1-5).  Every block is taken exactly once, each XCD's blocks ascend with q, top-down is bottom-up reversed."""
+
+    def blk(b, g, rev, sh):
+        per, q, x = g // 8, b >> 3, b & 7
+        if rev:
+            q = per - 1 - q
+        if sh == 0:
+            return x * per + q
+        full, grp = per >> sh, q >> sh
+        if grp < full:
+            return (grp << (sh + 3)) + (x << sh) + (q - (grp << sh))
+        r = per - (full << sh)
+        return (full << (sh + 3)) + x * r + (q - (full << sh))
+
+    for g in (8, 16, 64, 3912, 4096, 4104, 62504, 500000):
+        for sh in (0, 4, 6, 9):
+            per = g // 8
+            fwd = [blk(b, g, False, sh) for b in range(g)]
+            rev = [blk(b, g, True, sh) for b in range(g)]
+            assert sorted(fwd) == list(range(g)) and sorted(rev) == list(range(g))
+            for x in range(8):
+                f = [v for b, v in enumerate(fwd) if b & 7 == x]
+                r = [v for b, v in enumerate(rev) if b & 7 == x]
+                assert f == sorted(f) and r == f[::-1]
+                if sh == 0 or per <= (1 << sh):
+                    assert f == list(range(x * per, (x + 1) * per))

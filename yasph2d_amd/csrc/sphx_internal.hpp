@@ -90,6 +90,7 @@ struct Consts {
     // is far from the ends of the exponent range
     uint32_t q_noclamp;
     uint32_t nt_cold;  // outputs that nobody reads before the next step (density, alpha, warm-start sums, ids) are stored with the nontemporal hint
+    uint32_t xcd_shift;  // log2 of the XCD chunk length in blocks (xcd_bid; 0: contiguous eighths)
     uint32_t rev;  // this launch sweeps the particle blocks from the top down (xcd_bid; alternates from launch to launch, sphx_ctx::alternate_sweep)
 };
 
@@ -367,6 +368,7 @@ struct sphx_ctx {
     uint32_t tile_class_n = 0, tile_class_dt_bits = 0;
     bool tile_fix_owner = false;    // the re-grid's gather clears the owner bit of kept particles that left the own rectangle
     int fuse_div = 1;              // SPHX_FUSE_DIV=0: the divergence loop's first compute_density_change is never folded into the neighbour build
+    int xcd_chunk = -1;            // SPHX_XCD_CHUNK: log2 of the chunk length in blocks (0: contiguous eighths; -1: by size)
     int alternate_sweep = 1;       // SPHX_ALTERNATE_SWEEP=0: every launch sweeps the particle blocks bottom-up (rounds 1-5)
     int fuse_warm = 1;             // SPHX_FUSE_WARM=0: the divergence warm start is never folded into the neighbour build (A/B)
     bool div_error_fused = false;  // the latest neighbour build did that pass: the loop's first iteration skips it

@@ -168,16 +168,30 @@ __device__ __forceinline__ uint32_t entry_off(uint32_t w3, uint32_t u) { return 
 __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((size_t)(i >> 6) * 64 + k) * 64 + (i & 63u); }
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
-// and below is fetched into ~3 different L2s.  Here XCD x owns the x-th contiguous eighth of the particles — a compact patch
-// of the domain — in EVERY per-particle kernel, so neighbour gathers (and the next kernel's reads of what this one wrote) stay
-// in one L2.  Grids of these kernels are multiples of 8 (nblocks()).  Placement is a speed hint only, never a correctness one.
-// rev (round 6, Consts::rev): the launch sweeps its eighth of the particles from the top down.  Consecutive kernels of a step stream
+// and below is fetched into ~3 different L2s (+8 % per step at 16 M).  Rounds 1-5: XCD x owned the x-th contiguous EIGHTH of the
+// particles in every per-particle kernel.  Round 6: it owns every eighth CHUNK of up to 512 consecutive blocks (131 072 particles)
+// instead — still a compact patch of the domain per XCD (neighbour gathers and the next kernel's reads stay in one L2), but the eight
+// XCDs now work inside ONE moving band of ~1 M particles instead of at eight places 2 M particles apart: what one XCD's far gathers
+// and window edges need was just loaded by its neighbour XCD (Infinity Cache), and HBM sees one band of open pages: -1.0...-1.7 % per
+// step at 16 M on one box, nothing on another — and the XCDs share the WORK evenly when it is not spread evenly over the particles:
+// the 16 M step after 2 500 steps -9 % (profiles/r06_experiments/xcd_chunks.txt).
+// Grids of these kernels are multiples of 8 (nblocks()).  Placement is a speed hint only, never a correctness one.
+// rev (round 6, Consts::rev): the launch sweeps the blocks from the top down.  Consecutive kernels of a step stream
 // the same arrays; the Infinity Cache (256 MiB) and each XCD's L2 still hold what the previous launch touched LAST, which a launch that
 // starts at block 0 again reads last of all (after 800 MB of its own traffic): with alternating directions a launch starts where its
 // predecessor stopped.  A speed hint like the mapping itself; no result depends on it.
-__device__ __forceinline__ uint32_t xcd_bid(uint32_t rev = 0u) {
-    const uint32_t per = gridDim.x >> 3, q = blockIdx.x >> 3;
-    return (blockIdx.x & 7u) * per + (rev ? per - 1u - q : q);
+// shift = log2 of the chunk length in blocks (Consts::xcd_shift; 0: one contiguous eighth per XCD, the round 1-5 form), chosen by the
+// host from the context's size: ~1/8 of an XCD's share, between 64 and 512 blocks of 256 particles — at 1 M particles chunks of 64
+// (16 384 particles): the late window, where the pool costs more per particle than the splashes, -6 % (one XCD used to own the pool);
+// from t = 0, where every block costs the same, -1 %.
+__device__ __forceinline__ uint32_t xcd_bid(uint32_t rev = 0u, uint32_t shift = 0u) {
+    const uint32_t per = gridDim.x >> 3, q0 = blockIdx.x >> 3, x = blockIdx.x & 7u;
+    const uint32_t q = rev ? per - 1u - q0 : q0;
+    if (shift == 0u) return x * per + q;
+    const uint32_t full = per >> shift, g = q >> shift;
+    if (g < full) return (g << (shift + 3u)) + (x << shift) + (q - (g << shift));
+    const uint32_t r = per - (full << shift);  // the last, shorter group of chunks
+    return (full << (shift + 3u)) + x * r + (q - (full << shift));
 }
 
 // Gather base[idx] with a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address
@@ -673,7 +687,7 @@ __global__ __launch_bounds__(256) void k_key_count(PVr PV, const float2* __restr
                                                     uint32_t n, float dt, Consts K, GridView g, uint32_t* __restrict__ hist,
                                                     uint32_t* __restrict__ cidx, uint32_t* __restrict__ slot, uint32_t ring,
                                                     DevScalars* __restrict__ scal, uint32_t first) {
-    const uint32_t i = first + xcd_bid(K.rev) * 256 + threadIdx.x;
+    const uint32_t i = first + xcd_bid(K.rev, K.xcd_shift) * 256 + threadIdx.x;
     float2 p = make_float2(0.0f, 0.0f);
     if (i < n) {
         if (ADVECT) {
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ ci
                                                   uint32_t* __restrict__ hist, uint32_t rev) {
     // (lane t of a workgroup takes the particles b0 + t, b0 + 256 + t, ...: every load and every store of a wavefront is one run of
     // consecutive words — particles arrive nearly sorted, so consecutive particles go to consecutive slots)
-    const uint32_t b0 = xcd_bid(rev) * (256u * SCATTER_PER_LANE) + threadIdx.x;
+    const uint32_t b0 = xcd_bid(rev & 1u, rev >> 8) * (256u * SCATTER_PER_LANE) + threadIdx.x;  // (rev: bit 0 direction, bits 8.. chunk shift)
     if (b0 - threadIdx.x >= n) return;
     uint32_t w[SCATTER_PER_LANE];
 #pragma unroll
@@ -800,7 +814,7 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
     // is placed.  ONE is the default: unlike the scatter, whose lanes had a single 4-byte load each, this kernel has 24 bytes per slot
     // in flight and moves its bytes at 5.3 TB/s with one slot per lane — 126 / 128 / 145 us at 16 M with one / two / four
     // (profiles/r05_experiments/regrid.txt).
-    const uint32_t b0 = xcd_bid(rev) * (256u * GATHER_PER_LANE);
+    const uint32_t b0 = xcd_bid(rev & 1u, rev >> 8) * (256u * GATHER_PER_LANE);
     if (b0 >= n) return;
     // The words of order[] around p: a cell holds three or four particles, so the cell mates the ranking below looks at are almost
     // always among them — and so are the two ends of the cell (ORDER_HEAD; round 5: the cell index of the record and the cell's range
@@ -1433,7 +1447,7 @@ __device__ __forceinline__ void nb_tail(const float2* __restrict__ posA, uint32_
     const uint32_t cap = K.remote_cap / 4u;
     const uint32_t rbase = LIST_WIN + w * WAVE_REMOTE;
     // (wave-uniform bases in scalar registers: the stores below address them with 32-bit lane offsets)
-    uint32_t* const rtab = remote + ((size_t)xcd_bid(K.rev) * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
+    uint32_t* const rtab = remote + ((size_t)xcd_bid(K.rev, K.xcd_shift) * REMOTE_CAP + (uint32_t)__builtin_amdgcn_readfirstlane(w * WAVE_REMOTE));
     char* const slice = (char*)(list + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(i >> 6) * 4096);
     const uint32_t t_row0 = lds_addr(mytile);
     uint32_t run = 0;  // out-of-window entries of the staged rows so far (scalar)
@@ -1663,7 +1677,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     uint16_t* __restrict__ counts, uint32_t* __restrict__ wave, uint32_t* __restrict__ remote, float* __restrict__ density, float* __restrict__ alpha,
     DevScalars* __restrict__ scal, const uint32_t* __restrict__ n_dev, DivArgs dv) {
     if (n_dev) n = min(n, *n_dev);  // tile path: launched over an upper bound, see k_rank_gather
-    if (xcd_bid(K.rev) * 256 >= n) return;
+    if (xcd_bid(K.rev, K.xcd_shift) * 256 >= n) return;
     // (one object, the window first: at LDS offset 0 the four slots of a trip are one clamped base register + immediate offsets)
     struct Smem {
         float2 win[WIN_SLOTS + WIN_PAD];       // positions of the sorted particles around this workgroup's 256 (+ pad slots)
@@ -1677,11 +1691,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     uint32_t (*const tile)[STAGE_ROWS][64] = sm.tile;
     float2* const vwin = sm.vwin;
     float* const swin = sm.swin;
-    const uint32_t i = xcd_bid(K.rev) * 256 + threadIdx.x;
+    const uint32_t i = xcd_bid(K.rev, K.xcd_shift) * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // Stage the window with coalesced loads.  In Morton order most of a particle's 3x3-cell candidates lie within a few
     // hundred sorted slots, so the candidate scan below reads LDS instead of issuing ~40 scattered global loads per wave.
-    const uint32_t b0 = xcd_bid(K.rev) * 256;
+    const uint32_t b0 = xcd_bid(K.rev, K.xcd_shift) * 256;
     const uint32_t w0 = b0 > WIN_HALO ? b0 - WIN_HALO : 0u;
     const uint32_t wlen = min(b0 + 256u + WIN_HALO, n) - w0;
     SPHX_STAMP_BEGIN()
@@ -2200,7 +2214,7 @@ template <int KIND, bool DENSITY, bool ALPHA>
 __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict__ posA, uint32_t n, uint32_t soff, Consts K,
                                                         NbView nb, float* __restrict__ density, float* __restrict__ alpha) {
     __shared__ Stage<1, 0> rec;  // position
-    const uint32_t blk = xcd_bid(K.rev);
+    const uint32_t blk = xcd_bid(K.rev, K.xcd_shift);
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
@@ -2410,7 +2424,7 @@ __global__ __launch_bounds__(64) void k_publish_vmax(DevScalars* scal, VmaxArgs 
 __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                                       float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ Stage<2, 1> rec;  // position, velocity; density
-    const uint32_t blk = xcd_bid(K.rev);
+    const uint32_t blk = xcd_bid(K.rev, K.xcd_shift);
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     struct StageRec {
@@ -2521,7 +2535,7 @@ __device__ __forceinline__ float wcsph_pressure(const Consts& K, float local_den
 __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ density, uint32_t n, uint32_t soff, Consts K,
                                           float dt, NbView nb, float2* __restrict__ accel, DevScalars* __restrict__ scal, uint32_t vslot) {
     __shared__ Stage<2, 1> rec;  // position, velocity; density
-    const uint32_t blk = xcd_bid(K.rev);
+    const uint32_t blk = xcd_bid(K.rev, K.xcd_shift);
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     struct StageRec {
@@ -2619,7 +2633,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
     __shared__ Stage<2, 0> rec;  // position, velocity
     auto put = [&](uint32_t slot, const float4& r) { rec.put_vec01(slot, r); };
     auto take = [&](uint32_t o) { return rec.vec01(o); };
-    const uint32_t blk = xcd_bid(K.rev);
+    const uint32_t blk = xcd_bid(K.rev, K.xcd_shift);
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
     // this particle's scalars are requested together with everything else (one round trip, not two)
@@ -2806,7 +2820,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         }
         return L;
     };
-    const Loaded LA = load_block(xcd_bid(K.rev));
+    const Loaded LA = load_block(xcd_bid(K.rev, K.xcd_shift));
     if (LA.h.lwlen) nb_stage_store(LA.h, LA.st, [&](uint32_t slot, const StageRec& q, uint32_t) { store_rec(slot, q); });
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
