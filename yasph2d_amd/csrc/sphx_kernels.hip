@@ -169,9 +169,9 @@ __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((s
 // XCD-aware workgroup -> particle-range mapping.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
 // with the plain mapping every XCD walks the whole (Morton-ordered) array and a record gathered by neighbours in the rows above
 // and below is fetched into ~3 different L2s (+8 % per step at 16 M).  Rounds 1-5: XCD x owned the x-th contiguous EIGHTH of the
-// particles in every per-particle kernel.  Round 6: it owns every eighth CHUNK of up to 512 consecutive blocks (131 072 particles)
+// particles in every per-particle kernel.  Round 6: it owns every eighth CHUNK of 128 consecutive blocks (32 768 particles)
 // instead — still a compact patch of the domain per XCD (neighbour gathers and the next kernel's reads stay in one L2), but the eight
-// XCDs now work inside ONE moving band of ~1 M particles instead of at eight places 2 M particles apart: what one XCD's far gathers
+// XCDs now work inside ONE moving band of 262 144 particles instead of at eight places 2 M particles apart: what one XCD's far gathers
 // and window edges need was just loaded by its neighbour XCD (Infinity Cache), and HBM sees one band of open pages: -1.0...-1.7 % per
 // step at 16 M on one box, nothing on another — and the XCDs share the WORK evenly when it is not spread evenly over the particles:
 // the 16 M step after 2 500 steps -9 % (profiles/r06_experiments/xcd_chunks.txt).
@@ -180,10 +180,8 @@ __device__ __forceinline__ size_t ell_index(uint32_t i, uint32_t k) { return ((s
 // the same arrays; the Infinity Cache (256 MiB) and each XCD's L2 still hold what the previous launch touched LAST, which a launch that
 // starts at block 0 again reads last of all (after 800 MB of its own traffic): with alternating directions a launch starts where its
 // predecessor stopped.  A speed hint like the mapping itself; no result depends on it.
-// shift = log2 of the chunk length in blocks (Consts::xcd_shift; 0: one contiguous eighth per XCD, the round 1-5 form), chosen by the
-// host from the context's size: ~1/8 of an XCD's share, between 64 and 512 blocks of 256 particles — at 1 M particles chunks of 64
-// (16 384 particles): the late window, where the pool costs more per particle than the splashes, -6 % (one XCD used to own the pool);
-// from t = 0, where every block costs the same, -1 %.
+// shift = log2 of the chunk length in blocks (Consts::xcd_shift; 0: one contiguous eighth per XCD, the round 1-5 form; the host sets 7:
+// 128 blocks = 32 768 particles).
 __device__ __forceinline__ uint32_t xcd_bid(uint32_t rev = 0u, uint32_t shift = 0u) {
     const uint32_t per = gridDim.x >> 3, q0 = blockIdx.x >> 3, x = blockIdx.x & 7u;
     const uint32_t q = rev ? per - 1u - q0 : q0;
