@@ -135,6 +135,29 @@ def test_sixteen_million_disturbed_state_with_divergence_warm_start():
     _compare_full(ctx, o, "16 M disturbed, step 5", solver_state=True)
 
 
+@pytest.mark.parametrize("target", [64.0e6, 128.0e6])
+def test_multi_gpu_config_sizes_in_one_context_one_step_bit_exact(target):
+    """configs[3] and configs[4]'s particle counts (64 M, 128 M) fit ONE MI355X: the single context against the oracle at those sizes,
+    one step behind the warm-up — 27-bit slot numbers, the larger cell tables, the streaming-list and cold-store paths, every kernel of
+    the t = 0 step.  (The tiled runs of these sizes are compared with this single context in tests/test_gpu_multi.py.)"""
+    pos, boundary = dam_break(float(np.sqrt(target / 4050.0)))
+    assert 0.99 * target < len(pos) < 1.01 * target
+    ctx = y.SphxContext()
+    ctx.set_boundary(boundary)
+    ctx.upload(pos)
+    o = Oracle(omp=True)
+    o.set_boundary(boundary)
+    o.set_particles(pos)
+    del pos
+    timer = y.TimeManager()
+    st, dt_ns = step(ctx, timer)
+    so = o.dfsph_step()
+    assert dt_ns == o.timer_step_ns()
+    for k in ("density_iterations", "divergence_iterations", "warmstart_density", "warmstart_divergence", "neighbor_entries"):
+        assert st[k] == so[k], (k, st[k], so[k])
+    _compare_full(ctx, o, "%d M, step 1" % round(target / 1e6))
+
+
 @pytest.mark.parametrize("target,steps", [(1.0e6, 60), (16.0e6, 20)])
 def test_full_size_properties(target, steps):
     """Size-independent properties at BASELINE's full sizes (configs[1] = 1 M, configs[2] = 16 M): sortedness, permutation,
