@@ -217,6 +217,27 @@ __device__ __forceinline__ float4 ldpv(const PVr& v, uint32_t idx) {
     const float2 p = gat(v.pos, idx), u = gat(v.vel, idx);
     return make_float4(p.x, p.y, u.x, u.y);
 }
+// The records of TWO consecutive slots g, g + 1 (g even) in one 16-byte load per array.  A vector load of eight bytes or more per lane
+// holds the CU's address path for 16 cycles whatever its width or exec mask (a 4-byte one for ~4; tools/vmem_issue_bench.hip), so two
+// records per lane and instruction cost what one did.  Scalars (4 bytes) stay two loads.
+template <class R>
+struct Pair {
+    R a, b;
+};
+__device__ __forceinline__ Pair<float2> gat2(const float2* __restrict__ base, uint32_t g) {
+    const float4 q = gat((const float4*)base, g >> 1);
+    return Pair<float2>{make_float2(q.x, q.y), make_float2(q.z, q.w)};
+}
+// (4-byte scalars of two consecutive slots: ONE 8-byte load — two 4-byte loads of every other word would each span 512 bytes per
+// wavefront and cost 16 cycles like it.  g even; the caller guards arrays without a boundary tail: both slots or none.)
+__device__ __forceinline__ Pair<float> gat2(const float* __restrict__ base, uint32_t g) {
+    const float2 q = gat((const float2*)base, g >> 1);
+    return Pair<float>{q.x, q.y};
+}
+__device__ __forceinline__ Pair<float4> ldpv2(const PVr& v, uint32_t g) {
+    const Pair<float2> p = gat2(v.pos, g), u = gat2(v.vel, g);
+    return Pair<float4>{make_float4(p.a.x, p.a.y, u.a.x, u.a.y), make_float4(p.b.x, p.b.y, u.b.x, u.b.y)};
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions on the DPP data path (round 4).  A __shfl_xor butterfly is six ds_bpermute round trips with four vector
@@ -1281,6 +1302,26 @@ __device__ __forceinline__ void slots9n(const NbGrid& g, uint32_t cx, uint32_t c
         bx[d] = min((x >> BLOCK_SHIFT) - g.bx0, g.nbx1);  // (a coordinate below the rectangle wraps to a huge value: clamped too)
         row[d] = __umul24(min((y >> BLOCK_SHIFT) - g.by0, g.nby1), g.nbx);
     }
+    // A box that lies inside ONE 64 x 64 block (no cell of it on a block's rim) has all nine cells in that block's part of the table:
+    // slot = offset | ly[dy] | lx[dx] ascends with dx and with dy, and the seven-comparator network sorts it.  Any lane on a rim
+    // (36 % of the wavefronts of the dam break at t = 0, counted on the host): the full network for the wavefront.
+    const bool inside = ((cx & 63u) - 1u) < 62u && ((cy & 63u) - 1u) < 62u;
+    const bool all_inside = !__any(!inside);
+#ifndef SPHX_DIRN_NINE
+    if (all_inside) {
+        // ... and ONE directory entry: the eight other look-ups would return the same word, each holding the CU's address path like a
+        // load of 64 different ones (round 6, tools/vmem_issue_bench.hip)
+        const uint32_t off = gat(g.dirn, row[1] + bx[1]);
+        flags = off;
+        centre = off;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) slot[dy * 3 + dx] = (off & ~DIRN_FLAG) | (ly[dy] | lx[dx]);
+        sort9_monotone(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
+        return;
+    }
+#endif
     flags = 0;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -1291,22 +1332,29 @@ __device__ __forceinline__ void slots9n(const NbGrid& g, uint32_t cx, uint32_t c
             if (dx == 1 && dy == 1) centre = off;
             slot[dy * 3 + dx] = (off & ~DIRN_FLAG) | (ly[dy] | lx[dx]);  // offsets are multiples of 4096
         }
-    // A box that lies inside ONE 64 x 64 block (no cell of it on a block's rim) has all nine cells in that block's part of the table:
-    // slot = offset | ly[dy] | lx[dx] ascends with dx and with dy, and the seven-comparator network sorts it.  Any lane on a rim
-    // (36 % of the wavefronts of the dam break at t = 0, counted on the host): the full network for the wavefront.
-    const bool inside = ((cx & 63u) - 1u) < 62u && ((cy & 63u) - 1u) < 62u;
-    if (!__any(!inside))
+    if (all_inside)
         sort9_monotone(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
     else
         sort9(slot[0], slot[1], slot[2], slot[3], slot[4], slot[5], slot[6], slot[7], slot[8]);
 }
 __device__ __forceinline__ void ranges9n(const NbGrid& g, const uint32_t (&slot)[9], uint32_t (&s)[9], uint32_t (&e)[9]) {
+#ifndef SPHX_FINE_SPLIT
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint2 se = gat(g.fine, slot[t]);
         s[t] = se.x;
         e[t] = se.y;
     }
+#else
+    // (experiment, round 6: start and end as TWO 4-byte gathers — a 4-byte load of ~20 consecutive entries holds the CU's address path
+    // for ~4 cycles in tools/vmem_issue_bench.hip, an 8-byte one for 16.  No gain in the kernel: 494.6 against 491.7 us at 16 M.)
+    const uint32_t* const f32 = (const uint32_t*)g.fine;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        s[t] = gat(f32, 2u * slot[t]);
+        e[t] = gat(f32, 2u * slot[t] + 1u);
+    }
+#endif
 }
 
 // 8 waves per SIMD = 8 workgroups per CU: the staged rows (12 KiB) + the window (4 KiB; two of them in the form that also stages
@@ -1702,15 +1750,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     const float2 pi = gat(posA, live ? i : b0);  // own position straight from global memory: the cell look-ups below do not wait for the barrier
     constexpr uint32_t NWIN = (WIN_SLOTS + 255) / 256;
     float2 wreg[NWIN];
-#pragma unroll
-    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = gat(posA, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
     float2 vreg[MODE == 2 ? NWIN : 1];
     float2 vi = make_float2(0.0f, 0.0f);
+#ifdef SPHX_BUILD_SINGLE
+#pragma unroll
+    for (uint32_t u = 0; u < NWIN; ++u) wreg[u] = gat(posA, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
     if (MODE == 2) {
 #pragma unroll
         for (uint32_t u = 0; u < NWIN; ++u) vreg[u] = gat(dv.vel, w0 + min(threadIdx.x + u * 256u, wlen - 1u));
         vi = gat(dv.vel, live ? i : b0);
     }
+#else
+    // Round 6: TWO window slots per thread in one 16-byte load (slots w0 + 2t, w0 + 2t + 1; w0 is even) — as nb_stage_load does
+    static_assert(NWIN == 2 && (WIN_HALO & 1u) == 0u, "two slots per thread");
+    const uint32_t wpair = w0 + min(2u * threadIdx.x, (wlen - 1u) & ~1u);
+    {
+        const Pair<float2> q = gat2(posA, wpair);
+        wreg[0] = q.a, wreg[1] = q.b;
+    }
+    if (MODE == 2) {
+        const Pair<float2> q = gat2(dv.vel, wpair);
+        vreg[0] = q.a, vreg[1] = q.b;  // (the own velocity: from the window, behind the barrier)
+    }
+#endif
     float sreg[MODE == 3 ? NWIN : 1];
     float warm_i = 0.0f;
     if (MODE == 3) {
@@ -1753,17 +1815,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     if (scan) prefetch(0);
 #endif
 #pragma unroll
-    for (uint32_t u = 0; u < NWIN; ++u)
-        if (threadIdx.x + u * 256u < wlen) {
-            win[threadIdx.x + u * 256u] = wreg[u];
-            if (MODE == 2) vwin[threadIdx.x + u * 256u] = vreg[u];
-            // (MODE 3: the window holds k_j = 0.5 max(warm_j, lim) — the clamp of dfsph.rs:356-358 applied ONCE per staged record, by the
-            // same two operations the walk applied per neighbour until round 5)
-            if (MODE == 3) swin[threadIdx.x + u * 256u] = 0.5f * fmaxf(sreg[u], dv.lim);
+    for (uint32_t u = 0; u < NWIN; ++u) {
+#ifdef SPHX_BUILD_SINGLE
+        const uint32_t tw = threadIdx.x + u * 256u;
+#else
+        const uint32_t tw = 2u * threadIdx.x + u;
+#endif
+        if (tw < wlen) {
+            win[tw] = wreg[u];
+            if (MODE == 2) vwin[tw] = vreg[u];
         }
+        // (MODE 3: the window holds k_j = 0.5 max(warm_j, lim) — the clamp of dfsph.rs:356-358 applied ONCE per staged record, by the
+        // same two operations the walk applied per neighbour until round 5.  4-byte scalars: one slot per thread and round.)
+        if (MODE == 3 && threadIdx.x + u * 256u < wlen) swin[threadIdx.x + u * 256u] = 0.5f * fmaxf(sreg[u], dv.lim);
+    }
     // pad slots: a candidate read past the window's end finds a NaN position (rejected) until the re-read from global memory replaces it
     if (threadIdx.x < WIN_PAD) win[wlen + threadIdx.x] = make_float2(__uint_as_float(0x7FC00000u), 0.0f);
     __syncthreads();
+#ifndef SPHX_BUILD_SINGLE
+    if (MODE == 2 && live) vi = vwin[i - w0];
+#endif
     SPHX_STAMP(0)
     uint32_t ct = 0;
     if (scan) {
@@ -2027,16 +2098,30 @@ struct NbStaged {  // the records a thread has requested for the staging area: w
     R w[NB_NW], r[NB_NR];
     uint32_t g[NB_NR];  // [N|B] slots of the table lines
 };
-template <class L>
-__device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load) -> NbStaged<decltype(load(0u))> {
+// load2(g) -> Pair of the records of the slots g, g + 1 (g even): the window is requested two slots per thread (round 6; until then
+// one slot per thread in two rounds — SPHX_STAGE_SINGLE), thread t holds the slots lw0 + 2t, lw0 + 2t + 1 in w[0], w[1].
+template <class L, class L2>
+__device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, L2&& load2) -> NbStaged<decltype(load(0u))> {
     NbStaged<decltype(load(0u))> st;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t (&g)[NB_NR] = st.g;
+#ifdef SPHX_STAGE_SINGLE
+    (void)load2;
 #pragma unroll
     for (uint32_t u = 0; u < NB_NW; ++u) {
         const uint32_t t = threadIdx.x + u * 256u;
         st.w[u] = load(h.lw0 + min(t, h.lwlen ? h.lwlen - 1u : 0u));  // clamped, not predicated: no branch between the loads
     }
+#else
+    {
+        static_assert(NB_NW == 2 && (LIST_HALO & 1u) == 0u, "two slots per thread; the window starts at an even slot");
+        // (clamped, not predicated.  lw0 is even; the last pair may reach one slot past the window's end, i.e. at most one record past the
+        // END of an [N|B] array with an odd number of slots — never past its allocation: an odd count of 8-byte records does not end a page)
+        const auto pr = load2(h.lw0 + min(2u * threadIdx.x, (h.lwlen ? h.lwlen - 1u : 0u) & ~1u));
+        st.w[0] = pr.a;
+        st.w[1] = pr.b;
+    }
+#endif
     nb_head_late(h, nb, blk, i, n);  // (waits for the count word: everything that does not depend on it is in flight)
 #pragma unroll
     for (uint32_t u = 0; u < NB_NR; ++u) g[u] = h.g[u];
@@ -2046,8 +2131,18 @@ __device__ __forceinline__ auto nb_stage_load(NbHead& h, const NbView& nb, uint3
 #ifdef SPHX_ABL_NOREMOTE  // (traffic / timing experiments: the out-of-window records are NOT fetched — results are wrong)
     for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(h.lw0);
 #else
+#ifdef SPHX_REMOTE_ALWAYS
 #pragma unroll
     for (uint32_t u = 0; u < NB_NR; ++u) st.r[u] = load(lane + u * 64u < h.R ? g[u] : h.lw0);
+#else
+    // Round 6: the records of lines 64.. are only requested by a wavefront that has such lines (h.R: a scalar, long there — it was
+    // requested with the count word nb_head_late has just waited for).  A vector load of eight bytes or more per lane holds the CU's
+    // address path for 16 cycles whatever its exec mask (tools/vmem_issue_bench.hip): the second round cost every wavefront one such
+    // instruction per staged array, for nothing in the 9 of 10 wavefronts with fewer than 65 out-of-window neighbours.
+    st.r[0] = load(lane < h.R ? g[0] : h.lw0);
+    static_assert(NB_NR == 2, "two rounds of table lines");
+    if (h.R > 64u) st.r[1] = load(lane + 64u < h.R ? g[1] : h.lw0);
+#endif
 #endif
     return st;
 }
@@ -2056,16 +2151,20 @@ __device__ __forceinline__ void nb_stage_store(const NbHead& h, const NbStaged<R
     const uint32_t lane = threadIdx.x & 63u, wq = (threadIdx.x >> 6) * WAVE_REMOTE;
 #pragma unroll
     for (uint32_t u = 0; u < NB_NW; ++u) {
+#ifdef SPHX_STAGE_SINGLE
         const uint32_t t = threadIdx.x + u * 256u;
+#else
+        const uint32_t t = 2u * threadIdx.x + u;
+#endif
         if (t < h.lwlen) store(t, st.w[u], h.lw0 + t);
     }
 #pragma unroll
     for (uint32_t u = 0; u < NB_NR; ++u)
         if (lane + u * 64u < h.R) store(LIST_WIN + wq + lane + u * 64u, st.r[u], st.g[u]);
 }
-template <class L, class S>
-__device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, S&& store) {
-    const auto st = nb_stage_load(h, nb, blk, i, n, load);
+template <class L, class L2, class S>
+__device__ __forceinline__ void nb_stage(NbHead& h, const NbView& nb, uint32_t blk, uint32_t i, uint32_t n, L&& load, L2&& load2, S&& store) {
+    const auto st = nb_stage_load(h, nb, blk, i, n, load, load2);
     nb_stage_store(h, st, [&](uint32_t slot, const decltype(load(0u))& r, uint32_t) { store(slot, r); });
 }
 // Traversal of entries 0..lim-1 in list order.  gather_lds(o) -> record: o = BYTE offset of the entry's staging slot in a 4-byte
@@ -2215,7 +2314,7 @@ __global__ __launch_bounds__(256) void k_density_alpha(const float2* __restrict_
     const uint32_t blk = xcd_bid(K.rev, K.xcd_shift);
     const uint32_t i = blk * 256 + threadIdx.x;
     NbHead h = nb_head(nb, blk, i, n);
-    nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
+    nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return gat(posA, g); }, [&](uint32_t g) { return gat2(posA, g); }, [&](uint32_t slot, float2 r) { rec.put_vec<0>(slot, r); });
     __syncthreads();
     if (i >= n) return;
     const uint32_t oi = (i - h.lw0) * 4u;
@@ -2431,6 +2530,11 @@ __global__ NONP_BOUNDS void k_nonpressure(PVr PV, const float* __restrict__ dens
     };
     nb_stage(
         h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail (XSPH: dynamic neighbours only, dfsph.rs:456)
+        [&](uint32_t g) {
+            const Pair<float4> pv = ldpv2(PV, g);
+            const Pair<float> rho = gat2(density, g < soff ? g : 0u);  // (a pair that straddles soff: the second record is a boundary particle's, its density is not used)
+            return Pair<StageRec>{StageRec{pv.a, rho.a}, StageRec{pv.b, rho.b}};
+        },
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2542,6 +2646,11 @@ __global__ TRAV_BOUNDS void k_wcsph_accel(PVr PV, const float* __restrict__ dens
     };
     nb_stage(
         h, nb, blk, i, n, [&](uint32_t g) { return StageRec{ldpv(PV, g), gat(density, g < soff ? g : 0u)}; },  // density[] has no boundary tail; static entries do not use it
+        [&](uint32_t g) {
+            const Pair<float4> pv = ldpv2(PV, g);
+            const Pair<float> rho = gat2(density, g < soff ? g : 0u);  // (a pair that straddles soff: the second record is a boundary particle's, its density is not used)
+            return Pair<StageRec>{StageRec{pv.a, rho.a}, StageRec{pv.b, rho.b}};
+        },
         [&](uint32_t slot, const StageRec& r) {
             rec.put_vec01(slot, r.pv);
             rec.put_scal<0>(slot, r.rho);
@@ -2651,7 +2760,13 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         // (pa.va.enabled == 0 — tile path: dt is the host's, all-reduced over the tiles; no law here)
         uint32_t vb = 0;
         if (pa.va.enabled && threadIdx.x < STRIPES) vb = scal->vstripe[threadIdx.x].vmax[pa.va.vslot & 3u];
-        const NbStaged<PredRec> st = nb_stage_load(h, nb, blk, i, n, load_pred);
+        // (a pair that straddles soff: its second record is a boundary particle's, predicted() ignores the acceleration it got)
+        auto load_pred2 = [&](uint32_t g) {
+            const Pair<float4> pv = ldpv2(PV, g);
+            const Pair<float2> a = gat2(pa.accel, g < soff ? g : 0u);
+            return Pair<PredRec>{PredRec{pv.a, a.a}, PredRec{pv.b, a.b}};
+        };
+        const NbStaged<PredRec> st = nb_stage_load(h, nb, blk, i, n, load_pred, load_pred2);
         __shared__ float dt_s;
         if (pa.va.enabled && threadIdx.x < 64) {
             const uint32_t b = wave_max_u32(vb);
@@ -2666,7 +2781,7 @@ __global__ TRAV_BOUNDS void k_compute_error(PVr PV, const float* __restrict__ de
         }
         nb_stage_store(h, st, [&](uint32_t slot, const PredRec& r, uint32_t g) { put(slot, predicted(r, g)); });
     } else {
-        nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return ldpv(PV, g); }, put);
+        nb_stage(h, nb, blk, i, n, [&](uint32_t g) { return ldpv(PV, g); }, [&](uint32_t g) { return ldpv2(PV, g); }, put);
     }
     __syncthreads();
     float e = 0.0f, e_owned = 0.0f;
@@ -2772,13 +2887,17 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     // :188 / :309 / :339), and k_i + 0 = k_i to the bit (WARM: 0.5 max(0, lim) = 0, lim < 0) — so the walk adds (k_i + k_j) for every
     // entry and needs no "dynamic or static?" select per neighbour (round 4: add + compare + select, 10 cycles of ~100).  (k_i = -0
     // would become +0: the sign of a zero summand never reaches the sum, which starts from +0 and therefore is never -0.)
-    auto load_rec = [&](uint32_t g) {
-        const float w = gat(wsrc, g < soff ? g : 0u);
-        return StageRec{gat(posA, g), g < soff ? w : 0.0f};
+    // (the zero is selected when the record is STORED: a select behind the load would make the compiler wait for the load right
+    // there — inside the branch of nb_stage_load's second round of table lines)
+    auto load_rec = [&](uint32_t g) { return StageRec{gat(posA, g), gat(wsrc, g < soff ? g : 0u)}; };
+    auto load_rec2 = [&](uint32_t g) {
+        const Pair<float2> p = gat2(posA, g);
+        const Pair<float> w = gat2(wsrc, g < soff ? g : 0u);  // (a pair that straddles soff: store_rec zeroes the boundary record's scalar)
+        return Pair<StageRec>{StageRec{p.a, w.a}, StageRec{p.b, w.b}};
     };
-    auto store_rec = [&](uint32_t slot, const StageRec& q) {
+    auto store_rec = [&](uint32_t slot, const StageRec& q, uint32_t g) {
         rec.put_vec<0>(slot, q.p);
-        rec.put_scal<0>(slot, q.w);
+        rec.put_scal<0>(slot, g < soff ? q.w : 0.0f);
     };
     // Everything the block needs from global memory, requested in one go (Loaded).  (Round 5 tried workgroups that do TWO consecutive
     // blocks, the second block's requests going out before the first block's walk begins: 64 registers, eight workgroups per CU
@@ -2799,15 +2918,28 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         L.i = blk * 256 + threadIdx.x;
         L.h = nb_head(nb, blk, L.i, n);
         // (position and velocity of the own particle: two 8-byte loads; only the velocity is written back)
+#ifdef SPHX_CORRECT_POS_GLOBAL
         L.pvi = L.i < n ? ldpv(PVr{posA, vel}, L.i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
+        // (round 6: only the velocity — the position is in the window this workgroup stages, process() takes it from there: one 8-byte
+        // load per thread less, 16 cycles of the CU's address path per wavefront, tools/vmem_issue_bench.hip)
+        {
+            const float2 vi = gat((const float2*)vel, min(L.i, n ? n - 1u : 0u));
+            L.pvi = make_float4(0.0f, 0.0f, vi.x, vi.y);
+        }
+#endif
         // first: the first correction of its loop — the accumulated warm-start value starts from zero (dfsph.rs:206-208 / :361-363):
         // nothing is read, and nobody had to write that zero either
         L.warm_i = (L.i < n && !first) ? warm[L.i] : 0.0f;
         // (TILE — TileClassArgs in use: clamped, not predicated; behind a branch the compiler tests the owner bit inside it and waits there)
         L.id_i = TILE ? tc.pid[min(L.i, n - 1u)] : 0u;
-        L.st = nb_stage_load(L.h, nb, blk, L.i, n, load_rec);
+        L.st = nb_stage_load(L.h, nb, blk, L.i, n, load_rec, load_rec2);
         L.ahead = DirAhead{0xFFFFFFFFu, EMPTY};
+#ifdef SPHX_CORRECT_POS_GLOBAL
         if (!WARM && INV_DT && ca.hist) {
+#else
+        if (false) {  // (requested in process(), once the position is there)
+#endif
             // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, with the
             // staging loads in flight, for the block the particle is in BEFORE it moves (a particle rarely changes its 64 x 64 block)
             if (L.i < n) {
@@ -2819,7 +2951,7 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
         return L;
     };
     const Loaded LA = load_block(xcd_bid(K.rev, K.xcd_shift));
-    if (LA.h.lwlen) nb_stage_store(LA.h, LA.st, [&](uint32_t slot, const StageRec& q, uint32_t) { store_rec(slot, q); });
+    if (LA.h.lwlen) nb_stage_store(LA.h, LA.st, store_rec);
     if (judge) {
         constexpr bool DIVERGENCE = !INV_DT;
         residual_wave_reduce(hi, lo);
@@ -2860,14 +2992,27 @@ __global__ TRAV_BOUNDS void k_correct(float2* __restrict__ vel, const float2* __
     auto process = [&](const Loaded& L) {
     const uint32_t i = L.i, blk = L.blk;
     const NbHead& h = L.h;
-    const float4 pvi = L.pvi;
+    float4 pvi = L.pvi;
     const float warm_i = L.warm_i;
     const uint32_t id_i = L.id_i;
-    const DirAhead ahead = L.ahead;
+    DirAhead ahead = L.ahead;
     (void)blk;
     (void)id_i;
-    (void)ahead;
     __syncthreads();
+#ifndef SPHX_CORRECT_POS_GLOBAL
+    if (i < n) {
+        const float2 pi = h.wide ? gat(posA, i) : rec.vec<0>((i - h.lw0) * 4u);
+        pvi.x = pi.x, pvi.y = pi.y;
+        if (!WARM && INV_DT && ca.hist) {
+            // the cell count at the end of this kernel needs the directory entry of the particle's block: requested now, in front of the
+            // walk, for the block the particle is in BEFORE it moves (a particle rarely changes its 64 x 64 block)
+            uint32_t cx0, cy0;
+            cell_of(K, pi, cx0, cy0);
+            ahead = dir_ahead(ca.g, cx0, cy0);
+        }
+    }
+#endif
+    (void)ahead;
     float2 pnew = make_float2(0.0f, 0.0f);
     if (i < n) {
         const uint32_t ct = h.ct;
