@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -246,7 +247,8 @@ def main():
     ap.add_argument("--tolerance-scale", type=float, default=1.0,
                     help="multiply both solver tolerances (dfsph.rs:49,53) by this; < 1 makes the loops iterate (the iterating-regime window)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
-                    help="run a scratch context for this long before the measured one is created (GPU clocks / first-touch; 0 = off)")
+                    help="a scratch context keeps the GPU busy from this long before the measured context's first warm-up step until that step has "
+                         "returned (no idle gap in front of the timed region: BusyGpu; 0 = off)")
     ap.add_argument("--per-step-calls", action="store_true", help="timed region: one library call per step from Python instead of one call "
                     "that runs the K steps (sphx_solver_simulation_steps: the caller's frame loop, main.rs:348-350, inside the library)")
     ap.add_argument("--abi-calls", action="store_true", help="drive the two-phase C ABI from Python (one ctypes call per phase) instead of "
@@ -353,34 +355,65 @@ def main():
 
     import yasph2d_amd as y
 
-    state = {"prewarmed": False}
-
     def scene_of(particles_total):
         scale = float(np.sqrt(particles_total / 4050.0))
         w = y.FluidParticleWorld()
         w.reset_fluid(scale)
         return scale, w
 
-    def prewarm(particles):
-        # Clock / page warm-up on a SCRATCH context (its own small scene, destroyed before the measured one exists): a fresh box runs
-        # its first few hundred milliseconds of kernels at lower clocks, and W = 5 warm-up steps are 1 ms.  The measured context still
-        # does exactly --warmup untimed and --steps timed steps from t = 0.
-        if args.prewarm_ms <= 0 or state["prewarmed"]:
-            return
-        state["prewarmed"] = True
-        _, sw = scene_of(min(particles, 1_000_000))
-        sd = np.float32(2.0) * np.float32(sw.properties()["particle_radius"])
-        sctx = y.SphxContext(y.default_params(device=dev_index))
-        sctx.set_boundary(sw.boundary_particles)
-        sctx.upload(sw.positions)
-        stimer = y.TimeManager()
-        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(20):
-                v = sctx.step_begin(stimer.simulation_step(), stimer.law(sd))
-                sctx.step_finish(y.duration_as_secs_f32(stimer.update_simulation_step(sd, v)))
-        sctx.synchronize()
-        sctx.close()
+    class BusyGpu:
+        """Keeps the GPU busy, on a SCRATCH context with a scene of its own, from before the measured context's first warm-up step
+        until that step (the one that uploads) has returned.  Why: after ANY idle gap of a few milliseconds — and the host generating the
+        scene, allocating and copying 16 M particles is tens of them — this part's power management over-corrects: the steps behind the
+        gap cost up to 20 % more (the third one most), and it takes ~25 steps, 35 ms, until the step time has settled again
+        (tools/early_steps.py, profiles/r06_experiments/idle_gap_transient.txt: after 5 / 30 / 300 ms of idling alike; data do not
+        matter).  W = 5 warm-up steps are 7 ms, so a line timed behind them sat inside that transient, 3-4 % below the rate every later
+        window of the same run shows.  With the GPU never idle between the scratch steps and the measured context's second warm-up
+        step the timed region starts settled.  The measured context still does exactly --warmup untimed and --steps timed steps from
+        t = 0; the scratch context has stopped (joined, synchronised) before the timed region's first barrier."""
+
+        def __init__(self):
+            self.solver = None
+            self.thread = None
+            self.stop = threading.Event()
+
+        def start(self, particles):
+            if args.prewarm_ms <= 0:
+                return False
+            if self.solver is None:
+                # (a scene of the measured size up to 16 M: a light load settles the clocks for a light load)
+                _, self.w = scene_of(min(particles, 16_000_000))
+                self.solver = y.DFSPHSolver(self.w, y.default_params(device=dev_index))
+                self.timer = y.TimeManager()
+                self.solver.simulation_steps(self.w, self.timer, 2, sync_world=False)
+            self.stop.clear()
+
+            def loop():
+                while not self.stop.is_set():
+                    self.solver.simulation_steps(self.w, self.timer, 4, sync_world=False)  # (ctypes drops the GIL for the call)
+
+            self.thread = threading.Thread(target=loop, daemon=True)
+            self.thread.start()
+            time.sleep(args.prewarm_ms * 1e-3)
+            return True
+
+        def signal(self):
+            self.stop.set()
+
+        def join(self):
+            if self.thread is not None:
+                self.stop.set()
+                self.thread.join()
+                self.thread = None
+                self.solver.context().synchronize()
+
+        def close(self):
+            self.join()
+            if self.solver is not None:
+                self.solver.close()
+                self.solver = None
+
+    busy = BusyGpu()
 
     def make_params():
         params = y.default_params(device=dev_index, fixed_iterations=tuple(args.fixed_iterations))
@@ -442,12 +475,18 @@ def main():
         dominant, wprof = None, None
         for _ in range(skip_steps):
             one_step()
+        # (BusyGpu: behind --skip-steps untimed steps the GPU has been busy for long enough anyway)
+        kept_busy = skip_steps == 0 and warmup > 0 and busy.start(n)
         if want_roofline and warmup > 0:
             ctx.profile_reset()
             ctx.profile_filter(None)
             ctx.profile_enable(True)
-        for _ in range(warmup):
+        for k in range(warmup):
             one_step()
+            if k == 0 and kept_busy:
+                busy.signal()  # the upload is over: the remaining warm-up steps keep the GPU busy themselves
+        if kept_busy:
+            busy.join()
         if want_roofline and warmup > 0:
             ctx.profile_enable(False)
             wprof = ctx.profile_get()
@@ -598,7 +637,6 @@ def main():
 
     def single_window(particles, skip_steps, steps, warmup, want_roofline=True):
         """One measurement on ONE context: the dam-break scaled to `particles`, `skip_steps` untimed steps, warm-up, timed steps."""
-        prewarm(particles)
         scale, w = scene_of(particles)
         pos, boundary = w.positions, w.boundary_particles
         n = len(pos)
@@ -703,7 +741,7 @@ def main():
                             + (f", fixed iterations {tuple(args.fixed_iterations)}" if any(args.fixed_iterations) else "")
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
-                "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
+                "prewarm": f"a scratch context keeps the GPU busy from {args.prewarm_ms:.0f} ms before the first warm-up step until that step (the upload) has returned: no idle gap in front of the timed region (BusyGpu in bench.py)" if args.prewarm_ms > 0 else "none",
                 "particles_total": n_global,
                 "parallelism": "single GPU",
                 "mean_density_iterations": head["it"]["Id"], "mean_divergence_iterations": head["it"]["Iv"], "warmstart_rate": [head["it"]["Wd"], head["it"]["Wv"]],
@@ -733,6 +771,7 @@ def main():
                 if small.get("value") and out["cpu_baseline"].get("value"):
                     out["cpu_baseline"]["cost_per_particle_step_vs_1M"] = small["value"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
+        busy.close()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         return
 
@@ -740,7 +779,6 @@ def main():
     if args.solver == "wcsph":
         raise SystemExit("--solver wcsph runs on one GPU")
     # weak scaling: the global scene holds `particles` per GPU
-    prewarm(args.particles)
     scale, w = scene_of(args.particles * world)
     pos, boundary = w.positions, w.boundary_particles
     t_scene_done = time.perf_counter()
@@ -874,7 +912,7 @@ def main():
                             + (f", solver tolerances x{args.tolerance_scale}" if args.tolerance_scale != 1.0 else "") + ", two-phase step through the C ABI",
                 "particles_per_gpu": n,
                 "owned_particles_per_rank": owned,
-                "prewarm": f"{args.prewarm_ms:.0f} ms of steps on a scratch context before the measured context was created" if args.prewarm_ms > 0 else "none",
+                "prewarm": f"a scratch context keeps the GPU busy from {args.prewarm_ms:.0f} ms before the first warm-up step until that step (the upload) has returned: no idle gap in front of the timed region (BusyGpu in bench.py)" if args.prewarm_ms > 0 else "none",
                 "particles_total": n_global,
                 "transport": minfo["transport"],
                 "setup_seconds": setup_seconds,
@@ -907,6 +945,7 @@ def main():
         if roof:
             out["roofline"] = roof
         sys.stdout.flush()
+        busy.close()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     # tiles, their communicator and the shared-memory segment of the scalar all-reduce (rank 0 unlinks it)
     comm_obj = getattr(multi, "_comm", None)
