@@ -559,6 +559,10 @@ def main():
                 "per_kernel_ms_per_step_event_inflated": {k: v["total_ms"] / extra for k, v in sorted(prof.items())},
                 "note": "per_kernel_ms_per_step_event_inflated brackets EVERY launch with events (which keeps kernels from overlapping their "
                         "neighbours' tails): its sum exceeds ms_per_step; information only",
+                "vs_rocprofv3": "avg_launch_ms is taken on the settled GPU the line is timed on (config.prewarm).  The committed rocprofv3 "
+                                "passes of this command run WITHOUT the scratch context (its launches would be averaged in): "
+                                "profiles/r06_stats_16M.txt averages 22 steps from t = 0, i.e. the transient behind the upload (~8 % above); "
+                                "profiles/r06_stats_16M_settled_steps45-64.txt is the same pass over steps 45-64 and agrees",
             }
             # Whole-step ledger per kernel: HBM bytes per launch from the committed counter passes of THESE kernels (hash-gated like
             # `traffic`), launch duration and launches per step live from this run's every-launch pass (event-inflated, see note).
